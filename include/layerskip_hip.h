@@ -1,0 +1,186 @@
+/*
+ * layerskip_hip.h -- C ABI of the MI355X-native self-speculative decoding engine.
+ *
+ * This is the drop-in boundary for the reference's hot path (facebookresearch/LayerSkip,
+ * self_speculation/):  the Python `GenerationStrategy` subclass in
+ * layerskip_amd/self_speculation/ binds these symbols with ctypes exactly where the reference
+ * calls into HF transformers / torch ATen.  Every entry point that replaces a reference function
+ * cites it (file:line relative to the reference tree).  No torch types cross this boundary:
+ * only raw device pointers (`void*` obtained from `tensor.data_ptr()`), host pointers, sizes and
+ * a HIP stream handle (`void*`, 0 = the null stream).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; `lsk_last_error()` returns a
+ *     human readable message for the calling thread.  Nothing throws, nothing aborts.
+ *   - device memory is OWNED BY THE CALLER (PyTorch-ROCm tensors used as storage): the caller
+ *     allocates the workspace, the KV page pool and the packed weight buffers with the sizes the
+ *     `lsk_*_bytes` functions report and keeps them alive for the life of the engine.
+ *   - bf16 everywhere a dtype is not stated; fp32 accumulation inside every kernel.
+ *   - rows: at most LSK_MAX_ROWS (16) token rows per kernel pass (draft: 1, verify:
+ *     num_speculations+1); longer inputs (prompt prefill) are walked in 16-row chunks by the
+ *     engine.
+ */
+#ifndef LAYERSKIP_HIP_H
+#define LAYERSKIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSK_ABI_VERSION 1
+#define LSK_MAX_ROWS 16
+#define LSK_MAX_SPEC 15   /* num_speculations handled by one fused step (rows = spec + 1) */
+#define LSK_MAX_EOS 8
+
+/* Model / engine geometry.  Mirrors the fields of transformers.LlamaConfig the reference's
+ * forward functions depend on (llama_model_utils.py:155-391 via modeling_llama.py). */
+typedef struct lsk_config {
+    int32_t num_layers;       /* L  */
+    int32_t hidden;           /* H  */
+    int32_t intermediate;     /* I  */
+    int32_t n_heads;
+    int32_t n_kv_heads;
+    int32_t head_dim;         /* 64 or 128 */
+    int32_t vocab;            /* V, multiple of 16 */
+    float   rms_eps;
+    int32_t max_ctx;          /* tokens the KV pool can hold (multiple of page_size) */
+    int32_t page_size;        /* tokens per KV page: 128 */
+    int32_t max_prompt;       /* rows of the bulk (prefill) hidden-state buffer */
+    int32_t target_wgs;       /* workgroups per projection launch; 0 = default (256) */
+} lsk_config;
+
+typedef struct lsk_engine lsk_engine;
+
+/* Result of one speculation step; mirrors the 5-tuple returned by
+ * SelfSpeculativeGenerationStrategy.single_step_speculation
+ * (self_speculation_generator.py:223-229) plus the tokens the step emitted. */
+typedef struct lsk_step_result {
+    int32_t num_matches;                       /* number_of_matches            (SSG:190)      */
+    int32_t num_drafts;                        /* draft_output_ids.numel()     (SSG:228)      */
+    int32_t num_emitted;                       /* num_matches + 1              (SSG:204-205)  */
+    int32_t next_token;                        /* verified_tokens[n]           (SSG:203)      */
+    int32_t kv_len;                            /* KV length after crop         (SSG:219-221)  */
+    int32_t emitted[LSK_MAX_ROWS + 1];         /* draft[:n] + verified[n]                      */
+    int32_t draft_tokens[LSK_MAX_ROWS];        /* draft_output_ids             (SSG:142)      */
+    int32_t verified_tokens[LSK_MAX_ROWS + 1]; /* verified_tokens              (SSG:182)      */
+} lsk_step_result;
+
+const char* lsk_last_error(void);
+int lsk_abi_version(void);
+
+/* ---- sizes ---------------------------------------------------------------------------- */
+int lsk_workspace_bytes(const lsk_config* cfg, size_t* out_bytes);
+int lsk_kv_pool_bytes(const lsk_config* cfg, size_t* out_bytes);
+/* bytes of an nn.Linear weight [n_rows][k] in the packed MFMA-fragment layout */
+int lsk_packed_bytes(int32_t n_rows, int32_t k, size_t* out_bytes);
+
+/* ---- weight packing --------------------------------------------------------------------
+ * Re-lays an nn.Linear weight (row-major bf16 [n_rows][k], `ld_src` elements between rows) into
+ * 16x32 MFMA B-fragment tiles so that every wave-wide load in the projection kernels is one
+ * contiguous 1 KiB read.  Tile `t` of the source lands at destination tile
+ * `dst_tile_offset + t*dst_tile_stride` (used to interleave gate/up and to concatenate q|k|v).
+ * `rope_head_dim` > 0 additionally permutes the rows of every head so that RoPE partner
+ * features (i, i + head_dim/2) sit 8 columns apart inside one tile.
+ * Replaces: nothing in the reference (it reads HF's nn.Linear weights in place); done once. */
+int lsk_pack_linear(const void* src, int32_t n_rows, int32_t k, int32_t ld_src, void* dst,
+                    int32_t dst_tile_offset, int32_t dst_tile_stride, int32_t rope_head_dim,
+                    void* stream);
+
+/* ---- engine lifetime ---------------------------------------------------------------------- */
+int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t workspace_bytes,
+                      void* kv_pool, size_t kv_pool_bytes, lsk_engine** out);
+int lsk_engine_destroy(lsk_engine* e);
+
+/* Per-layer weights.  wqkv/wo/wgu/wdown are PACKED buffers (lsk_pack_linear):
+ *   wqkv  = [q (rope-permuted) | k (rope-permuted) | v]      rows: (n_heads + 2*n_kv_heads)*head_dim, k = H
+ *   wo    = o_proj                                            rows: H,   k = n_heads*head_dim
+ *   wgu   = gate/up interleaved by 16-row tile                rows: 2*I, k = H
+ *   wdown = down_proj                                         rows: H,   k = I
+ * norm1 / norm2 are the plain bf16 RMSNorm gains (input_layernorm / post_attention_layernorm). */
+int lsk_engine_set_layer(lsk_engine* e, int32_t layer, const void* wqkv, const void* wo,
+                         const void* wgu, const void* wdown, const void* norm1, const void* norm2);
+/* embed: plain bf16 [V][H]; final_norm: bf16 [H]; lm_head: PACKED [V][H];
+ * rope_cos / rope_sin: bf16 [rope_len][head_dim/2] (host-precomputed exactly as
+ * LlamaRotaryEmbedding.forward does, modeling_llama.py:113-127). */
+int lsk_engine_set_globals(lsk_engine* e, const void* embed, const void* final_norm,
+                           const void* lm_head, const void* rope_cos, const void* rope_sin,
+                           int32_t rope_len);
+/* Logical page -> physical page of the KV pool (host array, copied).  Default: identity. */
+int lsk_engine_set_block_table(lsk_engine* e, const int32_t* table, int32_t n_pages, void* stream);
+
+/* Forget all cached context: `past_key_values = None` (SSG:42, ARG:38). */
+int lsk_engine_reset(lsk_engine* e, void* stream);
+/* crop_past_key_values (llama_model_utils.py:134-149): a length-counter write, no data moves. */
+int lsk_engine_set_kv_len(lsk_engine* e, int32_t kv_len, void* stream);
+int lsk_engine_get_kv_len(lsk_engine* e, int32_t* kv_len);
+
+/* ---- fused fast paths (greedy, no logits processors) ---------------------------------------- */
+
+/* One call of SelfSpeculativeGenerationStrategy.single_step_speculation
+ * (self_speculation_generator.py:102-229), greedy branch:
+ *   draft loop  = forward_early x num_speculations (llama_model_utils.py:213-276), device resident,
+ *   verify      = forward_remainder                (llama_model_utils.py:280-391),
+ *   accept      = longest matching prefix          (SSG:186-190),
+ *   rollback    = crop_past_key_values             (SSG:219-221).
+ * `input_ids` (host) are the `prompt_len` >= 1 new tokens (`input_ids` of SSG:105): the whole
+ * prompt on the first call, the single next token afterwards.  Synchronous at return. */
+int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len,
+                  int32_t num_speculations, int32_t exit_layer, const int32_t* eos_token_ids,
+                  int32_t n_eos, lsk_step_result* out, void* stream);
+
+/* One iteration of AutoRegressiveGenerationStrategy.generate_token_ids' loop
+ * (autoregressive_generator.py:43-75), greedy: `forward` (llama_model_utils.py:155-209) when
+ * layer_end == num_layers, `forward_early` (early-exit-only decoding, ARG:44-51) otherwise;
+ * then decode_next_token(token_idx=-1) (llama_model_utils.py:109-122). */
+int lsk_ar_step(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int32_t layer_end,
+                int32_t* next_token, void* stream);
+
+/* ---- building blocks (slow path with logits processors / sampling, and kernel parity tests) -- */
+
+/* h[buffer][row_base + i] = embed_tokens(ids[i])  (llama_model_utils.py:182,242,310).
+ * buffer: 0 = the 16-row step buffer, 1 = the bulk (prompt) buffer. */
+int lsk_embed_rows(lsk_engine* e, const int32_t* ids, int32_t n, int32_t buffer, int32_t row_base,
+                   void* stream);
+/* Run decoder layers [layer_begin, layer_end) in place over rows [row_base, row_base+m) of
+ * `buffer`; row i sits at position kv_len + pos_offset + i and its K/V are appended there
+ * (LlamaDecoderLayer.forward, modeling_llama.py:295-324, as called from
+ * llama_model_utils.py:193,253,354,375).  m <= LSK_MAX_ROWS. */
+int lsk_run_layers(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, int32_t pos_offset,
+                   int32_t layer_begin, int32_t layer_end, void* stream);
+/* Final RMSNorm + lm_head (+ greedy argmax) over rows [row_base, row_base+m)
+ * (llama_model_utils.py:204-205, :271-273, :386-387; decode_next_token :120-122).
+ * logits_out: optional device fp32 [m][ld_logits] (values are bf16-rounded like the model dtype);
+ * tokens_out: optional HOST int32[m] (forces a stream sync). */
+int lsk_run_head(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, void* logits_out,
+                 int32_t ld_logits, int32_t* tokens_out, void* stream);
+/* Copy rows of a hidden-state buffer to / from caller device memory (bf16 [m][H]). */
+int lsk_read_rows(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, void* dst, void* stream);
+int lsk_write_rows(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, const void* src, void* stream);
+
+/* ---- single kernels, exported for parity tests and for bench.py's roofline timing ---------- */
+
+/* y[m][n_rows] = x[m][k] @ W^T with W packed; fp32 out (no rounding).  norm_w != NULL applies
+ * LlamaRMSNorm(x) first (modeling_llama.py:62-67). */
+int lsk_test_gemm(const void* x, int32_t m, int32_t k, const void* w_packed, int32_t n_rows,
+                  const void* norm_w, float eps, float* y, int32_t target_wgs, void* stream);
+/* Longest-prefix acceptance on raw token arrays (device int32): the wavefront-ballot kernel
+ * behind SSG:186-190.  result (device int32[2]) = {num_matches, num_drafts_effective}. */
+int lsk_test_accept(const int32_t* draft, const int32_t* verified, int32_t num_drafts,
+                    const int32_t* eos, int32_t n_eos, int32_t* result, void* stream);
+/* Time `iters` back-to-back launches of the gate/up projection kernel of `layer` (the dominant
+ * kernel of the path) with HIP events on `stream`; *ms_per_launch = average duration. */
+int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t iters, float* ms_per_launch,
+                    void* stream);
+
+/* Bracket every gate/up launch of the decode path with HIP events on the launch stream (enable=1),
+ * then read the summed duration and launch count (this also clears the recording). */
+int lsk_engine_set_profile(lsk_engine* e, int32_t enable);
+int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAYERSKIP_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of include/layerskip_hip.h (the C-ABI drop-in boundary).
+
+The shared library is built in-tree by ``layerskip_amd/build.py`` (hipcc, gfx950).  There is no
+CPU fallback: if the library is missing or a symbol is absent, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_void_p
+
+LSK_MAX_ROWS = 16
+LSK_MAX_SPEC = 15
+LSK_MAX_EOS = 8
+LSK_ABI_VERSION = 1
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblayerskip_hip.so")
+
+
+class LskConfig(ctypes.Structure):
+    _fields_ = [
+        ("num_layers", c_int32), ("hidden", c_int32), ("intermediate", c_int32), ("n_heads", c_int32),
+        ("n_kv_heads", c_int32), ("head_dim", c_int32), ("vocab", c_int32), ("rms_eps", c_float),
+        ("max_ctx", c_int32), ("page_size", c_int32), ("max_prompt", c_int32), ("target_wgs", c_int32),
+    ]
+
+
+class LskStepResult(ctypes.Structure):
+    _fields_ = [
+        ("num_matches", c_int32), ("num_drafts", c_int32), ("num_emitted", c_int32), ("next_token", c_int32),
+        ("kv_len", c_int32),
+        ("emitted", c_int32 * (LSK_MAX_ROWS + 1)),
+        ("draft_tokens", c_int32 * LSK_MAX_ROWS),
+        ("verified_tokens", c_int32 * (LSK_MAX_ROWS + 1)),
+    ]
+
+
+# name -> (restype, argtypes); exactly the symbols include/layerskip_hip.h declares
+PROTOTYPES = {
+    "lsk_last_error": (c_char_p, []),
+    "lsk_abi_version": (c_int32, []),
+    "lsk_workspace_bytes": (c_int32, [POINTER(LskConfig), POINTER(c_size_t)]),
+    "lsk_kv_pool_bytes": (c_int32, [POINTER(LskConfig), POINTER(c_size_t)]),
+    "lsk_packed_bytes": (c_int32, [c_int32, c_int32, POINTER(c_size_t)]),
+    "lsk_pack_linear": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_engine_create": (c_int32, [POINTER(LskConfig), c_void_p, c_size_t, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "lsk_engine_destroy": (c_int32, [c_void_p]),
+    "lsk_engine_set_layer": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lsk_engine_set_globals": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
+    "lsk_engine_set_block_table": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_void_p]),
+    "lsk_engine_reset": (c_int32, [c_void_p, c_void_p]),
+    "lsk_engine_set_kv_len": (c_int32, [c_void_p, c_int32, c_void_p]),
+    "lsk_engine_get_kv_len": (c_int32, [c_void_p, POINTER(c_int32)]),
+    "lsk_spec_step": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, POINTER(c_int32), c_int32,
+                                POINTER(LskStepResult), c_void_p]),
+    "lsk_ar_step": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, POINTER(c_int32), c_void_p]),
+    "lsk_embed_rows": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_run_layers": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_run_head": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
+    "lsk_read_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "lsk_write_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "lsk_test_gemm": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_int32, c_void_p]),
+    "lsk_test_accept": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "lsk_time_gateup": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p]),
+    "lsk_engine_set_profile": (c_int32, [c_void_p, c_int32]),
+    "lsk_engine_get_profile": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32)]),
+}
+
+_LIB = None
+
+
+class LskError(RuntimeError):
+    """An entry point of liblayerskip_hip.so returned a non-zero status."""
+
+
+def load(path: str | None = None) -> ctypes.CDLL:
+    """Load the HIP extension (once) and type every exported symbol.  Raises if anything is missing."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    path = path or LIB_PATH
+    import torch  # noqa: F401  -- loads the ROCm runtime (libamdhip64.so.7) the extension links against
+    if not os.path.exists(path):
+        raise LskError(
+            f"HIP extension not built: {path} is missing. Run `python -m layerskip_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback for the decoding engine.")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise LskError(f"{path} does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.lsk_abi_version() != LSK_ABI_VERSION:
+        raise LskError(f"ABI mismatch: library {lib.lsk_abi_version()} vs binding {LSK_ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load().lsk_last_error()
+        raise LskError(msg.decode("utf-8", "replace") if msg else f"liblayerskip_hip status {status}")

@@ -1,0 +1,780 @@
+// C-ABI implementation of include/layerskip_hip.h: host-side orchestration of the HIP kernels that
+// replace the reference's forward_early / forward_remainder / forward + accept + crop hot path.
+// gfx950 (MI355X) only.  No torch types: raw device pointers in, HIP launches on the caller's stream.
+#include "../../include/layerskip_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "lsk_attn.h"
+#include "lsk_common.h"
+#include "lsk_gemm.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int lsk_fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return lsk_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define LSK_TRY(expr)                \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != 0) return _r;      \
+    } while (0)
+
+extern "C" const char* lsk_last_error(void) { return g_err; }
+extern "C" int lsk_abi_version(void) { return LSK_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+// nn.Linear weight -> 16x32 MFMA B-fragment tiles.  One thread moves one lane-fragment (16 B).
+__global__ void lsk_pack_kernel(const bf16_t* __restrict__ src, int n_rows, int k, int ld_src, bf16_t* __restrict__ dst,
+                                int dst_tile_offset, int dst_tile_stride, int rope_hd) {
+    const int ksteps = k >> 5;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_tiles = (n_rows + 15) >> 4;
+    const long long total = (long long)n_tiles * ksteps * 64;
+    if (gid >= total) return;
+    const int lane = (int)(gid & 63);
+    const long long blk = gid >> 6;
+    const int s = (int)(blk % ksteps);
+    const int t = (int)(blk / ksteps);
+    const int rp = t * 16 + (lane & 15);          // row in packed order
+    int srow = rp;
+    if (rope_hd > 0) {
+        const int head = rp / rope_hd;
+        const int r = rp - head * rope_hd;
+        const int tt = r >> 4;
+        const int cc = r & 15;
+        const int feat = (cc < 8) ? (tt * 8 + cc) : ((rope_hd >> 1) + tt * 8 + (cc - 8));
+        srow = head * rope_hd + feat;
+    }
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.0f;
+    if (srow < n_rows) v = *(const bf16x8*)(src + (size_t)srow * ld_src + s * 32 + (lane >> 4) * 8);
+    const size_t dt = (size_t)dst_tile_offset + (size_t)t * dst_tile_stride;
+    *(bf16x8*)(dst + ((dt * ksteps + s) * 64 + lane) * 8) = v;
+}
+
+// h[row_base + i] = embed[tokens[i]]   (tokens on device)
+__global__ void lsk_embed_kernel(const bf16_t* __restrict__ embed, const int* __restrict__ tokens, int hidden, int vocab,
+                                 bf16_t* __restrict__ h) {
+    const int row = blockIdx.x;
+    int tok = tokens[row];
+    tok = min(max(tok, 0), vocab - 1);
+    const bf16x8* src = (const bf16x8*)(embed + (size_t)tok * hidden);
+    bf16x8* dst = (bf16x8*)(h + (size_t)row * hidden);
+    for (int i = threadIdx.x; i < hidden / 8; i += blockDim.x) dst[i] = src[i];
+}
+
+// final argmax over the per-workgroup partials of the lm_head kernel (lowest index wins ties)
+__global__ void lsk_argmax_finalize_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int n_parts,
+                                           int m, int* __restrict__ tokens_out) {
+    const int row = blockIdx.x;
+    if (row >= m) return;
+    float v = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n_parts; i += 64) {
+        const float ov = part_val[i * 16 + row];
+        const int oi = part_idx[i * 16 + row];
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    if (threadIdx.x == 0) tokens_out[row] = idx;
+}
+
+// Greedy acceptance = longest matching prefix (SSG:186-190) as ONE wavefront: every lane compares one
+// draft position, __ballot gathers the mismatch mask, the count of leading matches is a find-first-set.
+// A drafted EOS ends the draft (SSG:146-148): positions after it do not count as drafts.
+// result: [0] num_matches, [1] num_drafts, [2] next_token, [3] new kv_len, [4..] emitted tokens
+__global__ void lsk_accept_kernel(const int* __restrict__ draft, const int* __restrict__ verified, int num_drafts,
+                                  const int* __restrict__ eos, int n_eos, int prompt_len, StepState* st,
+                                  int* __restrict__ result) {
+    const int lane = threadIdx.x;
+    int d = -1, v = -2;
+    bool is_eos = false;
+    if (lane < num_drafts) {
+        d = draft[lane];
+        v = verified[lane];
+        for (int i = 0; i < n_eos; ++i) is_eos |= (d == eos[i]);
+    }
+    const unsigned long long eos_mask = __ballot(is_eos);
+    const int td = eos_mask ? min(num_drafts, (int)__ffsll((long long)eos_mask)) : num_drafts;
+    const unsigned long long mism = __ballot(lane < td && d != v) | (1ull << td);
+    const int n = (int)__ffsll((long long)mism) - 1;
+    if (lane == 0) {
+        const int next = verified[n];
+        result[0] = n;
+        result[1] = td;
+        result[2] = next;
+        int kv = 0;
+        if (st != nullptr) {
+            kv = st->kv_len + prompt_len + n;
+            st->kv_len = kv;
+            st->next_token = next;
+        }
+        result[3] = kv;
+        for (int i = 0; i < n; ++i) result[4 + i] = draft[i];
+        result[4 + n] = next;
+    }
+}
+
+__global__ void lsk_set_state_kernel(StepState* st, int kv_len, int add) {
+    if (add) st->kv_len += kv_len; else st->kv_len = kv_len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+struct LayerWeights {
+    const bf16_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr, *norm1 = nullptr, *norm2 = nullptr;
+};
+
+struct lsk_engine {
+    lsk_config cfg;
+    std::vector<LayerWeights> layers;
+    const bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    int rope_len = 0;
+    // device workspace carve
+    unsigned char* ws = nullptr;
+    size_t ws_bytes = 0;
+    StepState* state = nullptr;
+    int* zero = nullptr;          // constant 0 (position base of absolute-position passes)
+    int* block_table = nullptr;
+    int* row_tokens = nullptr;    // [17] token of each step row (row 0 = input token, row j = draft j)
+    int* verified = nullptr;      // [17]
+    int* eos = nullptr;           // [8]
+    int* result = nullptr;        // [4 + 17]
+    int* bulk_ids = nullptr;      // [max_prompt]
+    float* part_val = nullptr;    // [max_parts][16]
+    int* part_idx = nullptr;
+    bf16_t* hrow = nullptr;       // [16][H]
+    bf16_t* hbulk = nullptr;      // [max_prompt][H]
+    bf16_t* qbuf = nullptr;       // [16][n_heads*hd]
+    bf16_t* attn = nullptr;       // [16][n_heads*hd]
+    bf16_t* act = nullptr;        // [16][I]
+    bf16_t* kv_pool = nullptr;
+    size_t kv_layer_elems = 0;    // elements per layer (K and V)
+    size_t kv_half_elems = 0;     // elements of K (or V) per layer
+    int max_parts = 0;
+    int n_pages = 0;
+    int kv_len_host = 0;          // mirror of state->kv_len
+    int target_wgs = 256;
+    // profiling of the dominant kernel (gate/up projection)
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WsLayout {
+    size_t state, zero, block_table, row_tokens, verified, eos, result, bulk_ids, part_val, part_idx, hrow, hbulk, qbuf,
+        attn, act, total;
+    int max_parts, n_pages;
+};
+
+static int check_cfg(const lsk_config* c) {
+    if (!c) return lsk_fail("null config");
+    if (c->head_dim != 64 && c->head_dim != 128) return lsk_fail("head_dim %d unsupported (64 or 128)", c->head_dim);
+    if (c->hidden % 32 || c->intermediate % 32) return lsk_fail("hidden/intermediate must be multiples of 32");
+    if ((c->n_heads * c->head_dim) % 32) return lsk_fail("n_heads*head_dim must be a multiple of 32");
+    if (c->intermediate % 16) return lsk_fail("intermediate must be a multiple of 16");
+    if (c->n_heads % c->n_kv_heads) return lsk_fail("n_heads must be a multiple of n_kv_heads");
+    if (c->page_size <= 0 || c->page_size % 32) return lsk_fail("page_size must be a positive multiple of 32");
+    if (c->max_ctx <= 0 || c->max_ctx % c->page_size) return lsk_fail("max_ctx must be a positive multiple of page_size");
+    if (c->num_layers <= 0 || c->vocab <= 0 || c->max_prompt < 0) return lsk_fail("bad geometry");
+    return 0;
+}
+
+static WsLayout ws_layout(const lsk_config* c) {
+    WsLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const int n_tiles_head = (c->vocab + 15) / 16;
+    L.max_parts = n_tiles_head;   // worst case: one tile per workgroup
+    L.n_pages = c->max_ctx / c->page_size;
+    L.state = take(sizeof(StepState));
+    L.zero = take(64);
+    L.block_table = take(sizeof(int) * (size_t)L.n_pages);
+    L.row_tokens = take(sizeof(int) * 32);
+    L.verified = take(sizeof(int) * 32);
+    L.eos = take(sizeof(int) * 16);
+    L.result = take(sizeof(int) * 32);
+    L.bulk_ids = take(sizeof(int) * (size_t)(c->max_prompt + 16));
+    L.part_val = take(sizeof(float) * 16 * (size_t)L.max_parts);
+    L.part_idx = take(sizeof(int) * 16 * (size_t)L.max_parts);
+    L.hrow = take(2 * (size_t)LSK_MAX_ROWS * c->hidden);
+    L.hbulk = take(2 * (size_t)(c->max_prompt + 16) * c->hidden);
+    L.qbuf = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
+    L.attn = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
+    L.act = take(2 * (size_t)LSK_MAX_ROWS * c->intermediate);
+    L.total = off;
+    return L;
+}
+
+extern "C" int lsk_workspace_bytes(const lsk_config* cfg, size_t* out_bytes) {
+    LSK_TRY(check_cfg(cfg));
+    if (!out_bytes) return lsk_fail("null out");
+    *out_bytes = ws_layout(cfg).total;
+    return 0;
+}
+
+extern "C" int lsk_kv_pool_bytes(const lsk_config* cfg, size_t* out_bytes) {
+    LSK_TRY(check_cfg(cfg));
+    if (!out_bytes) return lsk_fail("null out");
+    // [layer][K|V][page][kv_head][slot][head_dim] bf16
+    *out_bytes = (size_t)cfg->num_layers * 2 * (size_t)cfg->max_ctx * cfg->n_kv_heads * cfg->head_dim * 2;
+    return 0;
+}
+
+extern "C" int lsk_packed_bytes(int32_t n_rows, int32_t k, size_t* out_bytes) {
+    if (n_rows <= 0 || k <= 0 || (k % 32)) return lsk_fail("lsk_packed_bytes: n_rows=%d k=%d (k must be a multiple of 32)", n_rows, k);
+    *out_bytes = (size_t)((n_rows + 15) / 16) * 16 * (size_t)k * 2;
+    return 0;
+}
+
+extern "C" int lsk_pack_linear(const void* src, int32_t n_rows, int32_t k, int32_t ld_src, void* dst, int32_t dst_tile_offset,
+                               int32_t dst_tile_stride, int32_t rope_head_dim, void* stream) {
+    if (!src || !dst) return lsk_fail("lsk_pack_linear: null pointer");
+    if (n_rows <= 0 || k <= 0 || (k % 32)) return lsk_fail("lsk_pack_linear: k=%d must be a positive multiple of 32", k);
+    if (rope_head_dim > 0 && ((rope_head_dim % 32) || (n_rows % rope_head_dim))) return lsk_fail("lsk_pack_linear: bad rope_head_dim");
+    const long long total = (long long)((n_rows + 15) / 16) * (k / 32) * 64;
+    const int threads = 256;
+    const long long blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(lsk_pack_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)src, n_rows, k,
+                       ld_src, (bf16_t*)dst, dst_tile_offset, dst_tile_stride, rope_head_dim);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static const size_t kMaxGemmLds = 160 * 1024;
+
+template <int PRO, int EPI>
+static int set_gemm_attr() {
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    return 0;
+}
+
+static int init_kernel_attrs() {
+    static bool done = false;
+    if (done) return 0;
+    LSK_TRY((set_gemm_attr<PRO_PLAIN, EPI_F32>()));
+    LSK_TRY((set_gemm_attr<PRO_RMS, EPI_F32>()));
+    LSK_TRY((set_gemm_attr<PRO_PLAIN, EPI_RESID>()));
+    LSK_TRY((set_gemm_attr<PRO_RMS, EPI_SWIGLU>()));
+    LSK_TRY((set_gemm_attr<PRO_RMS, EPI_QKV>()));
+    LSK_TRY((set_gemm_attr<PRO_RMS, EPI_HEAD>()));
+    done = true;
+    return 0;
+}
+
+extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t workspace_bytes, void* kv_pool, size_t kv_pool_bytes,
+                                 lsk_engine** out) {
+    LSK_TRY(check_cfg(cfg));
+    if (!workspace || !kv_pool || !out) return lsk_fail("lsk_engine_create: null pointer");
+    WsLayout L = ws_layout(cfg);
+    size_t kvb = 0;
+    lsk_kv_pool_bytes(cfg, &kvb);
+    if (workspace_bytes < L.total) return lsk_fail("workspace too small: %zu < %zu", workspace_bytes, L.total);
+    if (kv_pool_bytes < kvb) return lsk_fail("kv pool too small: %zu < %zu", kv_pool_bytes, kvb);
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)kv_pool & 255)) return lsk_fail("workspace / kv pool must be 256-byte aligned");
+    LSK_TRY(init_kernel_attrs());
+    lsk_engine* e = new (std::nothrow) lsk_engine();
+    if (!e) return lsk_fail("out of host memory");
+    e->cfg = *cfg;
+    e->layers.resize(cfg->num_layers);
+    e->ws = (unsigned char*)workspace;
+    e->ws_bytes = workspace_bytes;
+    e->state = (StepState*)(e->ws + L.state);
+    e->zero = (int*)(e->ws + L.zero);
+    e->block_table = (int*)(e->ws + L.block_table);
+    e->row_tokens = (int*)(e->ws + L.row_tokens);
+    e->verified = (int*)(e->ws + L.verified);
+    e->eos = (int*)(e->ws + L.eos);
+    e->result = (int*)(e->ws + L.result);
+    e->bulk_ids = (int*)(e->ws + L.bulk_ids);
+    e->part_val = (float*)(e->ws + L.part_val);
+    e->part_idx = (int*)(e->ws + L.part_idx);
+    e->hrow = (bf16_t*)(e->ws + L.hrow);
+    e->hbulk = (bf16_t*)(e->ws + L.hbulk);
+    e->qbuf = (bf16_t*)(e->ws + L.qbuf);
+    e->attn = (bf16_t*)(e->ws + L.attn);
+    e->act = (bf16_t*)(e->ws + L.act);
+    e->kv_pool = (bf16_t*)kv_pool;
+    e->kv_half_elems = (size_t)cfg->max_ctx * cfg->n_kv_heads * cfg->head_dim;
+    e->kv_layer_elems = 2 * e->kv_half_elems;
+    e->max_parts = L.max_parts;
+    e->n_pages = L.n_pages;
+    e->target_wgs = cfg->target_wgs > 0 ? cfg->target_wgs : 256;
+    // identity block table, zeroed state
+    std::vector<int> table(L.n_pages);
+    for (int i = 0; i < L.n_pages; ++i) table[i] = i;
+    hipError_t err = hipMemcpy(e->block_table, table.data(), sizeof(int) * L.n_pages, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
+    if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
+    if (err != hipSuccess) { delete e; return lsk_fail("engine init copy failed: %s", hipGetErrorString(err)); }
+    *out = e;
+    return 0;
+}
+
+extern "C" int lsk_engine_destroy(lsk_engine* e) {
+    if (!e) return 0;
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    delete e;
+    return 0;
+}
+
+extern "C" int lsk_engine_set_layer(lsk_engine* e, int32_t layer, const void* wqkv, const void* wo, const void* wgu, const void* wdown,
+                                    const void* norm1, const void* norm2) {
+    if (!e || layer < 0 || layer >= e->cfg.num_layers) return lsk_fail("lsk_engine_set_layer: bad layer %d", layer);
+    if (!wqkv || !wo || !wgu || !wdown || !norm1 || !norm2) return lsk_fail("lsk_engine_set_layer: null weight");
+    LayerWeights& lw = e->layers[layer];
+    lw.wqkv = (const bf16_t*)wqkv; lw.wo = (const bf16_t*)wo; lw.wgu = (const bf16_t*)wgu; lw.wdown = (const bf16_t*)wdown;
+    lw.norm1 = (const bf16_t*)norm1; lw.norm2 = (const bf16_t*)norm2;
+    return 0;
+}
+
+extern "C" int lsk_engine_set_globals(lsk_engine* e, const void* embed, const void* final_norm, const void* lm_head, const void* rope_cos,
+                                      const void* rope_sin, int32_t rope_len) {
+    if (!e || !embed || !final_norm || !lm_head || !rope_cos || !rope_sin) return lsk_fail("lsk_engine_set_globals: null pointer");
+    if (rope_len < e->cfg.max_ctx) return lsk_fail("rope table (%d) shorter than max_ctx (%d)", rope_len, e->cfg.max_ctx);
+    e->embed = (const bf16_t*)embed; e->final_norm = (const bf16_t*)final_norm; e->lm_head = (const bf16_t*)lm_head;
+    e->rope_cos = (const bf16_t*)rope_cos; e->rope_sin = (const bf16_t*)rope_sin; e->rope_len = rope_len;
+    return 0;
+}
+
+extern "C" int lsk_engine_set_block_table(lsk_engine* e, const int32_t* table, int32_t n_pages, void* stream) {
+    if (!e || !table || n_pages != e->n_pages) return lsk_fail("lsk_engine_set_block_table: expected %d pages", e ? e->n_pages : -1);
+    for (int i = 0; i < n_pages; ++i)
+        if (table[i] < 0 || table[i] >= e->n_pages) return lsk_fail("block table entry %d out of range", i);
+    HIP_OK(hipMemcpyAsync(e->block_table, table, sizeof(int) * n_pages, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+static int set_kv_len(lsk_engine* e, int kv_len, bool add, hipStream_t st) {
+    hipLaunchKernelGGL(lsk_set_state_kernel, dim3(1), dim3(1), 0, st, e->state, kv_len, add ? 1 : 0);
+    HIP_OK(hipGetLastError());
+    e->kv_len_host = add ? e->kv_len_host + kv_len : kv_len;
+    return 0;
+}
+
+extern "C" int lsk_engine_reset(lsk_engine* e, void* stream) {
+    if (!e) return lsk_fail("null engine");
+    return set_kv_len(e, 0, false, (hipStream_t)stream);
+}
+
+extern "C" int lsk_engine_set_kv_len(lsk_engine* e, int32_t kv_len, void* stream) {
+    if (!e || kv_len < 0 || kv_len > e->cfg.max_ctx) return lsk_fail("lsk_engine_set_kv_len: %d out of range", kv_len);
+    return set_kv_len(e, kv_len, false, (hipStream_t)stream);
+}
+
+extern "C" int lsk_engine_get_kv_len(lsk_engine* e, int32_t* kv_len) {
+    if (!e || !kv_len) return lsk_fail("null pointer");
+    *kv_len = e->kv_len_host;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+static int ready(lsk_engine* e) {
+    if (!e) return lsk_fail("null engine");
+    if (!e->embed) return lsk_fail("engine globals not bound (lsk_engine_set_globals)");
+    for (size_t i = 0; i < e->layers.size(); ++i)
+        if (!e->layers[i].wqkv) return lsk_fail("layer %zu not bound (lsk_engine_set_layer)", i);
+    return 0;
+}
+
+static int tiles_per_wg(int n_units, int target_wgs) {   // units = tiles (or gate/up pairs)
+    int t = (n_units + target_wgs - 1) / target_wgs;
+    return t < 1 ? 1 : (t > 8 ? 8 : t);
+}
+
+template <int PRO, int EPI>
+static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_out = nullptr) {
+    const int unit = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int n_units = p.n_tiles / unit;
+    p.tiles_per_wg = tiles_per_wg(n_units, target_wgs) * unit;
+    const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
+    if (lds > kMaxGemmLds) return lsk_fail("gemm LDS %zu exceeds %zu", lds, kMaxGemmLds);
+    hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+    HIP_OK(hipGetLastError());
+    if (grid_out) *grid_out = grid;
+    return 0;
+}
+
+static bf16_t* buf_rows(lsk_engine* e, int buffer, int row_base) {
+    return (buffer == 0 ? e->hrow : e->hbulk) + (size_t)row_base * e->cfg.hidden;
+}
+
+static int check_rows(lsk_engine* e, int buffer, int row_base, int m) {
+    if (buffer != 0 && buffer != 1) return lsk_fail("bad buffer %d", buffer);
+    if (m < 1 || m > LSK_MAX_ROWS) return lsk_fail("row count %d out of range 1..%d", m, LSK_MAX_ROWS);
+    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
+    if (row_base < 0 || row_base + m > cap) return lsk_fail("rows [%d,%d) exceed buffer %d capacity %d", row_base, row_base + m, buffer, cap);
+    return 0;
+}
+
+static int launch_attn(lsk_engine* e, AttnParams& ap, hipStream_t st) {
+    const int hd = e->cfg.head_dim;
+    const int M = ap.M;
+    const int rm = (M == 1) ? 1 : (M <= 4 ? 4 : 8);
+    const size_t lds = (size_t)LSK_WAVES * rm * (hd + 2) * sizeof(float);
+    const dim3 grid(e->cfg.n_heads), block(LSK_THREADS);
+#define LSK_ATTN_CASE(HD, RM) hipLaunchKernelGGL((lsk_attn_kernel<HD, RM>), grid, block, lds, st, ap)
+    if (hd == 128) {
+        if (rm == 1) LSK_ATTN_CASE(128, 1); else if (rm == 4) LSK_ATTN_CASE(128, 4); else LSK_ATTN_CASE(128, 8);
+    } else {
+        if (rm == 1) LSK_ATTN_CASE(64, 1); else if (rm == 4) LSK_ATTN_CASE(64, 4); else LSK_ATTN_CASE(64, 8);
+    }
+#undef LSK_ATTN_CASE
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static int profile_event(lsk_engine* e, hipStream_t st) {
+    if (e->ev_used == e->ev_pool.size()) {
+        hipEvent_t ev;
+        HIP_OK(hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
+    HIP_OK(hipEventRecord(e->ev_pool[e->ev_used++], st));
+    return 0;
+}
+
+// decoder layers [lb, le) in place over rows of `x` (positions *base_ptr + pos_off + i)
+static int run_layers(lsk_engine* e, bf16_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st) {
+    const lsk_config& c = e->cfg;
+    const int qdim = c.n_heads * c.head_dim;
+    const int kvdim = c.n_kv_heads * c.head_dim;
+    for (int l = lb; l < le; ++l) {
+        const LayerWeights& lw = e->layers[l];
+        bf16_t* kpool = e->kv_pool + (size_t)l * e->kv_layer_elems;
+        bf16_t* vpool = kpool + e->kv_half_elems;
+        {   // input RMSNorm -> q/k/v projections -> RoPE -> KV append
+            GemmParams p{};
+            p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden;
+            p.N = qdim + 2 * kvdim; p.n_tiles = p.N / 16;
+            p.wp = lw.wqkv; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
+            p.norm_w = lw.norm1; p.eps = c.rms_eps;
+            p.q_out = e->qbuf; p.ldq = qdim; p.kpool = kpool; p.vpool = vpool; p.block_table = e->block_table;
+            p.page_size = c.page_size; p.n_heads = c.n_heads; p.n_kv = c.n_kv_heads; p.head_dim = c.head_dim;
+            p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin; p.kv_len = base_ptr; p.pos_off = pos_off;
+            LSK_TRY((launch_gemm<PRO_RMS, EPI_QKV>(p, e->target_wgs, st)));
+        }
+        {
+            AttnParams ap{};
+            ap.q = e->qbuf; ap.ldq = qdim; ap.out = e->attn; ap.ldo = qdim; ap.kpool = kpool; ap.vpool = vpool;
+            ap.block_table = e->block_table; ap.page_size = c.page_size; ap.n_kv = c.n_kv_heads;
+            ap.group = c.n_heads / c.n_kv_heads; ap.M = m; ap.kv_len = base_ptr; ap.pos_off = pos_off;
+            ap.scale_log2e = (float)((1.0 / sqrt((double)c.head_dim)) * 1.4426950408889634);
+            LSK_TRY(launch_attn(e, ap, st));
+        }
+        {   // o_proj + residual
+            GemmParams p{};
+            p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
+            p.wp = lw.wo; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
+            p.h = x; p.ldh = c.hidden;
+            LSK_TRY((launch_gemm<PRO_PLAIN, EPI_RESID>(p, e->target_wgs, st)));
+        }
+        {   // post-attention RMSNorm -> gate/up -> SiLU * up
+            GemmParams p{};
+            p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
+            p.wp = lw.wgu; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
+            p.norm_w = lw.norm2; p.eps = c.rms_eps; p.act = e->act; p.ldact = c.intermediate;
+            if (e->profile) LSK_TRY(profile_event(e, st));
+            LSK_TRY((launch_gemm<PRO_RMS, EPI_SWIGLU>(p, e->target_wgs, st)));
+            if (e->profile) LSK_TRY(profile_event(e, st));
+        }
+        {   // down_proj + residual
+            GemmParams p{};
+            p.x = e->act; p.ldx = c.intermediate; p.M = m; p.K = c.intermediate; p.N = c.hidden; p.n_tiles = p.N / 16;
+            p.wp = lw.wdown; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
+            p.h = x; p.ldh = c.hidden;
+            LSK_TRY((launch_gemm<PRO_PLAIN, EPI_RESID>(p, e->target_wgs, st)));
+        }
+    }
+    return 0;
+}
+
+// final norm + lm_head + argmax over rows of x; tokens land in tokens_dev[0..m)
+static int run_head(lsk_engine* e, const bf16_t* x, int m, float* logits, int ld_logits, int* tokens_dev, hipStream_t st) {
+    const lsk_config& c = e->cfg;
+    GemmParams p{};
+    p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = c.vocab; p.n_tiles = (c.vocab + 15) / 16;
+    p.wp = e->lm_head; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
+    p.norm_w = e->final_norm; p.eps = c.rms_eps;
+    p.logits = logits; p.ld_logits = ld_logits; p.part_val = e->part_val; p.part_idx = e->part_idx;
+    int grid = 0;
+    LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, e->target_wgs, st, &grid)));
+    if (grid > e->max_parts) return lsk_fail("internal: head grid %d > max_parts %d", grid, e->max_parts);
+    hipLaunchKernelGGL(lsk_argmax_finalize_kernel, dim3(m), dim3(64), 0, st, e->part_val, e->part_idx, grid, m, tokens_dev);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static int embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, bf16_t* dst, hipStream_t st) {
+    hipLaunchKernelGGL(lsk_embed_kernel, dim3(n), dim3(256), 0, st, e->embed, tokens_dev, e->cfg.hidden, e->cfg.vocab, dst);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// rows [0, n) of the bulk buffer (already embedded or holding exit hiddens) through layers [lb, le),
+// 16 rows per pass, row r at position *base_ptr + r.
+static int run_bulk(lsk_engine* e, int n, const int* base_ptr, int lb, int le, hipStream_t st) {
+    for (int r0 = 0; r0 < n; r0 += LSK_MAX_ROWS) {
+        const int m = (n - r0) < LSK_MAX_ROWS ? (n - r0) : LSK_MAX_ROWS;
+        LSK_TRY(run_layers(e, e->hbulk + (size_t)r0 * e->cfg.hidden, m, base_ptr, r0, lb, le, st));
+    }
+    return 0;
+}
+
+static int check_ids(lsk_engine* e, const int32_t* ids, int n) {
+    for (int i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= e->cfg.vocab) return lsk_fail("token id %d at %d out of range [0,%d)", ids[i], i, e->cfg.vocab);
+    return 0;
+}
+
+extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t num_speculations, int32_t exit_layer,
+                             const int32_t* eos_token_ids, int32_t n_eos, lsk_step_result* out, void* stream) {
+    LSK_TRY(ready(e));
+    hipStream_t st = (hipStream_t)stream;
+    const lsk_config& c = e->cfg;
+    const int P = prompt_len, S = num_speculations, E = exit_layer, L = c.num_layers;
+    if (!input_ids || !out) return lsk_fail("lsk_spec_step: null pointer");
+    if (P < 1 || P - 1 > c.max_prompt) return lsk_fail("prompt_len %d out of range (max_prompt %d)", P, c.max_prompt);
+    if (S < 0 || S > LSK_MAX_SPEC) return lsk_fail("num_speculations %d out of range 0..%d", S, LSK_MAX_SPEC);
+    if (E < 1 || E > L) return lsk_fail("exit_layer %d out of range 1..%d", E, L);
+    if (n_eos < 0 || n_eos > LSK_MAX_EOS) return lsk_fail("n_eos %d out of range 0..%d", n_eos, LSK_MAX_EOS);
+    if (n_eos > 0 && !eos_token_ids) return lsk_fail("null eos_token_ids");
+    const int C = e->kv_len_host;
+    if (C + P + S > c.max_ctx) return lsk_fail("context overflow: %d + %d + %d > max_ctx %d", C, P, S, c.max_ctx);
+    LSK_TRY(check_ids(e, input_ids, P));
+
+    if (P > 1) HIP_OK(hipMemcpyAsync(e->bulk_ids, input_ids, sizeof(int) * (P - 1), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
+    if (n_eos > 0) HIP_OK(hipMemcpyAsync(e->eos, eos_token_ids, sizeof(int) * n_eos, hipMemcpyHostToDevice, st));
+
+    const int* kvp = &e->state->kv_len;
+    // ---- forward_early over the prompt rows that are not the last one (LMU:213-276, rows 0..P-2) ----
+    if (P > 1) {
+        LSK_TRY(embed_rows_dev(e, e->bulk_ids, P - 1, e->hbulk, st));
+        LSK_TRY(run_bulk(e, P - 1, kvp, 0, E, st));
+    }
+    // ---- draft loop (SSG:127-148), device resident: row j = input token (j = 0) or draft j ----
+    for (int j = 0; j <= S; ++j) {
+        bf16_t* xr = e->hrow + (size_t)j * c.hidden;
+        LSK_TRY(embed_rows_dev(e, e->row_tokens + j, 1, xr, st));
+        LSK_TRY(run_layers(e, xr, 1, kvp, P - 1 + j, 0, E, st));   // j == S: forward_remainder's early pass (LMU:350-362)
+        if (j < S) LSK_TRY(run_head(e, xr, 1, nullptr, 0, e->row_tokens + j + 1, st));
+    }
+    // ---- forward_remainder, late layers (LMU:364-383): exit_query_cache rows + last draft row ----
+    if (P > 1) LSK_TRY(run_bulk(e, P - 1, kvp, E, L, st));
+    LSK_TRY(run_layers(e, e->hrow, S + 1, kvp, P - 1, E, L, st));
+    LSK_TRY(run_head(e, e->hrow, S + 1, nullptr, 0, e->verified, st));
+    // ---- accept + rollback (SSG:186-221) ----
+    hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, st, e->row_tokens + 1, e->verified, S, e->eos, n_eos, P, e->state, e->result);
+    HIP_OK(hipGetLastError());
+    int host_res[4 + LSK_MAX_ROWS + 1];
+    int host_draft[LSK_MAX_ROWS + 1];
+    int host_ver[LSK_MAX_ROWS + 1];
+    HIP_OK(hipMemcpyAsync(host_res, e->result, sizeof(host_res), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(host_draft, e->row_tokens + 1, sizeof(int) * LSK_MAX_ROWS, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(host_ver, e->verified, sizeof(int) * (LSK_MAX_ROWS + 1), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    memset(out, 0, sizeof(*out));
+    out->num_matches = host_res[0];
+    out->num_drafts = host_res[1];
+    out->num_emitted = host_res[0] + 1;
+    out->next_token = host_res[2];
+    out->kv_len = host_res[3];
+    for (int i = 0; i <= host_res[0]; ++i) out->emitted[i] = host_res[4 + i];
+    for (int i = 0; i < S; ++i) out->draft_tokens[i] = host_draft[i];
+    for (int i = 0; i <= S; ++i) out->verified_tokens[i] = host_ver[i];
+    e->kv_len_host = host_res[3];
+    return 0;
+}
+
+extern "C" int lsk_ar_step(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int32_t layer_end, int32_t* next_token, void* stream) {
+    LSK_TRY(ready(e));
+    hipStream_t st = (hipStream_t)stream;
+    const lsk_config& c = e->cfg;
+    if (!input_ids || !next_token) return lsk_fail("lsk_ar_step: null pointer");
+    if (n_ids < 1 || n_ids - 1 > c.max_prompt) return lsk_fail("n_ids %d out of range", n_ids);
+    if (layer_end < 1 || layer_end > c.num_layers) return lsk_fail("layer_end %d out of range", layer_end);
+    if (e->kv_len_host + n_ids > c.max_ctx) return lsk_fail("context overflow");
+    LSK_TRY(check_ids(e, input_ids, n_ids));
+    const int P = n_ids;
+    if (P > 1) HIP_OK(hipMemcpyAsync(e->bulk_ids, input_ids, sizeof(int) * (P - 1), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
+    const int* kvp = &e->state->kv_len;
+    if (P > 1) {
+        LSK_TRY(embed_rows_dev(e, e->bulk_ids, P - 1, e->hbulk, st));
+        LSK_TRY(run_bulk(e, P - 1, kvp, 0, layer_end, st));
+    }
+    LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, e->hrow, st));
+    LSK_TRY(run_layers(e, e->hrow, 1, kvp, P - 1, 0, layer_end, st));
+    LSK_TRY(run_head(e, e->hrow, 1, nullptr, 0, e->verified, st));
+    LSK_TRY(set_kv_len(e, P, true, st));
+    HIP_OK(hipMemcpyAsync(next_token, e->verified, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ---- building blocks -------------------------------------------------------------------------------
+extern "C" int lsk_embed_rows(lsk_engine* e, const int32_t* ids, int32_t n, int32_t buffer, int32_t row_base, void* stream) {
+    LSK_TRY(ready(e));
+    if (!ids || n < 1) return lsk_fail("lsk_embed_rows: bad arguments");
+    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
+    if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base + n > cap) return lsk_fail("lsk_embed_rows: rows out of range");
+    if (n > e->cfg.max_prompt + 16) return lsk_fail("lsk_embed_rows: too many ids");
+    LSK_TRY(check_ids(e, ids, n));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemcpyAsync(e->bulk_ids, ids, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    return embed_rows_dev(e, e->bulk_ids, n, buf_rows(e, buffer, row_base), st);
+}
+
+extern "C" int lsk_run_layers(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, int32_t pos_offset, int32_t layer_begin,
+                              int32_t layer_end, void* stream) {
+    LSK_TRY(ready(e));
+    LSK_TRY(check_rows(e, buffer, row_base, m));
+    if (layer_begin < 0 || layer_end > e->cfg.num_layers || layer_begin > layer_end) return lsk_fail("bad layer range [%d,%d)", layer_begin, layer_end);
+    if (pos_offset < 0 || e->kv_len_host + pos_offset + m > e->cfg.max_ctx) return lsk_fail("positions exceed max_ctx");
+    return run_layers(e, buf_rows(e, buffer, row_base), m, &e->state->kv_len, pos_offset, layer_begin, layer_end, (hipStream_t)stream);
+}
+
+extern "C" int lsk_run_head(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, void* logits_out, int32_t ld_logits,
+                            int32_t* tokens_out, void* stream) {
+    LSK_TRY(ready(e));
+    LSK_TRY(check_rows(e, buffer, row_base, m));
+    if (logits_out && ld_logits < e->cfg.vocab) return lsk_fail("ld_logits %d < vocab %d", ld_logits, e->cfg.vocab);
+    hipStream_t st = (hipStream_t)stream;
+    LSK_TRY(run_head(e, buf_rows(e, buffer, row_base), m, (float*)logits_out, ld_logits, e->verified, st));
+    if (tokens_out) {
+        HIP_OK(hipMemcpyAsync(tokens_out, e->verified, sizeof(int) * m, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+extern "C" int lsk_read_rows(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, void* dst, void* stream) {
+    if (!e || !dst || m < 1) return lsk_fail("lsk_read_rows: bad arguments");
+    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
+    if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base + m > cap) return lsk_fail("lsk_read_rows: rows out of range");
+    HIP_OK(hipMemcpyAsync(dst, buf_rows(e, buffer, row_base), (size_t)m * e->cfg.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int lsk_write_rows(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, const void* src, void* stream) {
+    if (!e || !src || m < 1) return lsk_fail("lsk_write_rows: bad arguments");
+    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
+    if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base + m > cap) return lsk_fail("lsk_write_rows: rows out of range");
+    HIP_OK(hipMemcpyAsync(buf_rows(e, buffer, row_base), src, (size_t)m * e->cfg.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- single kernels for parity tests / roofline timing -------------------------------------------------
+extern "C" int lsk_test_gemm(const void* x, int32_t m, int32_t k, const void* w_packed, int32_t n_rows, const void* norm_w, float eps,
+                             float* y, int32_t target_wgs, void* stream) {
+    if (!x || !w_packed || !y) return lsk_fail("lsk_test_gemm: null pointer");
+    if (m < 1 || m > LSK_MAX_ROWS || k <= 0 || (k % 32) || n_rows <= 0) return lsk_fail("lsk_test_gemm: bad shape m=%d k=%d n=%d", m, k, n_rows);
+    LSK_TRY(init_kernel_attrs());
+    GemmParams p{};
+    p.x = (const bf16_t*)x; p.ldx = k; p.M = m; p.K = k; p.N = n_rows; p.n_tiles = (n_rows + 15) / 16;
+    p.wp = (const bf16_t*)w_packed; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * k * 2);
+    p.norm_w = (const bf16_t*)norm_w; p.eps = eps; p.y = y;
+    const int tw = target_wgs > 0 ? target_wgs : 256;
+    return norm_w ? launch_gemm<PRO_RMS, EPI_F32>(p, tw, (hipStream_t)stream) : launch_gemm<PRO_PLAIN, EPI_F32>(p, tw, (hipStream_t)stream);
+}
+
+extern "C" int lsk_test_accept(const int32_t* draft, const int32_t* verified, int32_t num_drafts, const int32_t* eos, int32_t n_eos,
+                               int32_t* result, void* stream) {
+    if (!draft || !verified || !result) return lsk_fail("lsk_test_accept: null pointer");
+    if (num_drafts < 0 || num_drafts > 63) return lsk_fail("lsk_test_accept: num_drafts %d out of range", num_drafts);
+    hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, draft, verified, num_drafts, eos, n_eos, 1,
+                       (StepState*)nullptr, result);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t iters, float* ms_per_launch, void* stream) {
+    LSK_TRY(ready(e));
+    if (layer < 0 || layer >= e->cfg.num_layers || m < 1 || m > LSK_MAX_ROWS || iters < 1 || !ms_per_launch) return lsk_fail("lsk_time_gateup: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const lsk_config& c = e->cfg;
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+    HIP_OK(hipEventRecord(a, st));
+    for (int i = 0; i < iters; ++i) {
+        const LayerWeights& lw = e->layers[(layer + i) % c.num_layers];
+        GemmParams p{};
+        p.x = e->hrow; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
+        p.wp = lw.wgu; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
+        p.norm_w = lw.norm2; p.eps = c.rms_eps; p.act = e->act; p.ldact = c.intermediate;
+        LSK_TRY((launch_gemm<PRO_RMS, EPI_SWIGLU>(p, e->target_wgs, st)));
+    }
+    HIP_OK(hipEventRecord(b, st));
+    HIP_OK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_per_launch = ms / iters;
+    return 0;
+}
+
+extern "C" int lsk_engine_set_profile(lsk_engine* e, int32_t enable) {
+    if (!e) return lsk_fail("null engine");
+    e->profile = enable != 0;
+    e->ev_used = 0;
+    return 0;
+}
+
+// Sum of the durations of every gate/up launch bracketed since lsk_engine_set_profile(e, 1).
+extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches) {
+    if (!e || !total_ms || !launches) return lsk_fail("null pointer");
+    float total = 0.f;
+    int n = 0;
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        float ms = 0.f;
+        HIP_OK(hipEventSynchronize(e->ev_pool[i + 1]));
+        HIP_OK(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
+        total += ms;
+        ++n;
+    }
+    *total_ms = total;
+    *launches = n;
+    e->ev_used = 0;
+    return 0;
+}

@@ -1,0 +1,98 @@
+// Shared device helpers and kernel parameter blocks of the MI355X self-speculative decoding engine.
+// gfx950 only: 64-wide wavefronts, v_mfma_f32_16x16x32_bf16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define LSK_WAVES 8            // waves per projection workgroup (split-K factor inside a WG)
+#define LSK_THREADS 512
+#define LSK_KC_STEPS 128       // 32-wide k-steps per K-chunk of a workgroup (= 4096 features)
+#define LSK_KC_ELEMS 4096
+#define LSK_SPW 16             // k-steps per wave per (tile, chunk) unit = depth of the weight ring
+#define LSK_ROWS 16
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }   // round-to-nearest-even
+// One rounding to the model dtype, result widened again (the reference rounds wherever HF's
+// bf16 modules materialise a tensor).
+__device__ __forceinline__ float rbf(float v) { return (float)((bf16_t)v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- projection (skinny GEMM) -----------------------------------------------------------------
+enum { PRO_PLAIN = 0, PRO_RMS = 1 };
+enum { EPI_F32 = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_HEAD = 4 };
+
+struct GemmParams {
+    const bf16_t* x;        // [M][ldx] input rows
+    int ldx;
+    int M;                  // 1..16
+    int K;                  // multiple of 32
+    const bf16_t* wp;       // packed weight tiles [n_tiles][K/32][64][8]
+    unsigned wp_bytes;
+    int N;                  // logical output features (rows of the nn.Linear weight)
+    int n_tiles;            // ceil(N / 16)
+    int tiles_per_wg;       // <= 8 (<= 16 for SWIGLU: 8 gate/up pairs)
+    const bf16_t* norm_w;   // PRO_RMS gain [K]
+    float eps;
+    // EPI_F32
+    float* y;               // [M][N]
+    // EPI_RESID: h[row][n] = bf16(h + bf16(acc))
+    bf16_t* h;
+    int ldh;
+    // EPI_SWIGLU: act[row][p*16+c]
+    bf16_t* act;
+    int ldact;
+    // EPI_QKV
+    bf16_t* q_out;          // [M][n_heads*head_dim]
+    int ldq;
+    bf16_t* kpool;          // this layer's K pages [page][n_kv][page_size][head_dim]
+    bf16_t* vpool;
+    const int* block_table;
+    int page_size;
+    int n_heads;
+    int n_kv;
+    int head_dim;
+    const bf16_t* rope_cos; // [rope_len][head_dim/2]
+    const bf16_t* rope_sin;
+    const int* kv_len;      // device scalar: verified context length C
+    int pos_off;            // row i sits at position *kv_len + pos_off + i
+    // EPI_HEAD
+    float* logits;          // optional [M][ld_logits] fp32 (bf16-rounded values)
+    int ld_logits;
+    float* part_val;        // [grid][16]
+    int* part_idx;          // [grid][16]
+};
+
+// ---- decode attention ---------------------------------------------------------------------------
+struct AttnParams {
+    const bf16_t* q;        // [M][ldq]
+    int ldq;
+    bf16_t* out;            // [M][ldo]
+    int ldo;
+    const bf16_t* kpool;
+    const bf16_t* vpool;
+    const int* block_table;
+    int page_size;
+    int n_kv;
+    int group;              // n_heads / n_kv
+    int M;
+    const int* kv_len;
+    int pos_off;
+    float scale_log2e;      // head_dim^-0.5 * log2(e)
+};
+
+struct StepState {
+    int kv_len;             // verified context length (all layers)
+    int next_token;
+    int pad[14];
+};

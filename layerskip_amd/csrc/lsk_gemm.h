@@ -1,0 +1,291 @@
+// Skinny projection kernel: y[M<=16][N] = f(x)[M][K] @ W[N][K]^T, W streamed once from HBM.
+//
+// The path is HBM-bound (M <= 16 rows => <= 16 FLOP per weight byte, ridge ~310), so the kernel is
+// built around the weight stream, not the math:
+//   * weights are pre-packed into 16(n) x 32(k) MFMA B-fragment tiles (lsk_pack_linear): every
+//     wave-wide load is ONE contiguous 1 KiB non-temporal buffer_load_dwordx4, straight to VGPRs
+//     (no LDS round trip: each byte is used by exactly one wave, once);
+//   * a workgroup = 8 waves that split K between them (wave w owns a contiguous run of <= 16
+//     k-steps of every 4096-wide K-chunk).  Each wave keeps a 16-deep ring of weight fragments in
+//     flight (16 KiB / wave, 128 KiB / workgroup) and refills a slot the moment the MFMA consumed it,
+//     across tile and chunk boundaries, so the HBM pipe never drains inside a launch;
+//   * the activation rows (1..16, RMSNorm fused) are staged once per K-chunk in LDS as bf16 rows and
+//     fed to v_mfma_f32_16x16x32_bf16 as the A operand; the 8 per-wave partial tiles are reduced
+//     through a double-buffered 8 KiB LDS slab (one barrier per tile) in a fixed order;
+//   * out-of-range ring slots use the buffer descriptor's bounds check (returns 0, moves no bytes),
+//     which keeps every s_waitcnt vmcnt static without wasting bandwidth on ragged K;
+//   * the epilogue (bf16 rounding + residual / SwiGLU / RoPE + KV append / argmax) runs in the
+//     owner wave straight from the accumulator registers.
+// Per output element the summation order depends only on K (never on M or on the other rows), so a
+// row computed in a 1-row draft pass is bit-identical to the same row in a 7-row verify pass.
+#pragma once
+#include "lsk_common.h"
+
+struct UnitInfo {
+    unsigned off0;   // byte offset of this wave's first block of the unit (+ lane*16)
+    int nvalid;      // valid k-steps of this wave in the unit (0..16)
+    int c;           // K-chunk index
+    int tl;          // tile index inside the workgroup
+    int ks0;         // first k-step (inside the chunk) of this wave
+    int steps_c;     // k-steps of the chunk
+};
+
+__device__ __forceinline__ UnitInfo lsk_unit_info(int u, int units, int ntl, int ksteps, int tile0, int w, int lane) {
+    UnitInfo r;
+    if (u >= units) { r.off0 = 0; r.nvalid = 0; r.c = 0; r.tl = 0; r.ks0 = 0; r.steps_c = 1; return r; }
+    const int c = u / ntl;
+    const int tl = u - c * ntl;
+    const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
+    const int spw = (steps_c + LSK_WAVES - 1) / LSK_WAVES;
+    const int ks0 = w * spw;
+    r.c = c; r.tl = tl; r.ks0 = ks0; r.steps_c = steps_c;
+    r.nvalid = max(0, min(spw, steps_c - ks0));
+    r.off0 = ((unsigned)(tile0 + tl) * (unsigned)ksteps + (unsigned)(c * LSK_KC_STEPS + ks0)) * 1024u + (unsigned)lane * 16u;
+    return r;
+}
+
+#define LSK_OOB_OFFSET 0xF0000000u
+
+// LDS carve (bytes)
+#define LSK_LDS_SLAB 0          // [2][8][256] f32 = 16384
+#define LSK_LDS_RED 16384       // [16][8] f32 = 512
+#define LSK_LDS_INV 16896       // [16] f32
+#define LSK_LDS_BESTV 17408     // [16][16] f32 = 1024
+#define LSK_LDS_BESTI 18432     // [16][16] i32 = 1024
+#define LSK_LDS_X 20480         // M rows of xstride bytes
+
+__host__ __device__ inline int lsk_gemm_xstride(int K) { return (K < LSK_KC_ELEMS ? K : LSK_KC_ELEMS) * 2 + 16; }
+__host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS_X + (size_t)M * lsk_gemm_xstride(K); }
+
+template <int PRO>
+__device__ __forceinline__ void lsk_stage_chunk(const GemmParams& p, unsigned char* xs, int xstride, const float* inv,
+                                                int c, int steps_c, int tid) {
+    const int e0 = tid * 8;
+    if (e0 < steps_c * 32) {
+        const int k0 = c * LSK_KC_ELEMS + e0;
+        bf16x8 nw;
+        if (PRO == PRO_RMS) nw = *(const bf16x8*)(p.norm_w + k0);
+        for (int r = 0; r < p.M; ++r) {
+            bf16x8 v = *(const bf16x8*)(p.x + (size_t)r * p.ldx + k0);
+            if (PRO == PRO_RMS) {
+                const float s = inv[r];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xn = rbf(bf2f(v[j]) * s);           // x32 * rsqrt(var + eps) -> model dtype
+                    v[j] = f2bf(bf2f(nw[j]) * xn);                   // weight * that, rounded again
+                }
+            }
+            *(bf16x8*)(xs + (size_t)r * xstride + e0 * 2) = v;
+        }
+    }
+}
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* slab = (float*)(smem + LSK_LDS_SLAB);
+    float* red = (float*)(smem + LSK_LDS_RED);
+    float* inv = (float*)(smem + LSK_LDS_INV);
+    unsigned char* xs = smem + LSK_LDS_X;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ksteps = p.K >> 5;
+    const int nchunks = (ksteps + LSK_KC_STEPS - 1) / LSK_KC_STEPS;
+    const int tile0 = blockIdx.x * p.tiles_per_wg;
+    const int ntl = min(p.tiles_per_wg, p.n_tiles - tile0);
+    const int units = nchunks * ntl;
+    const int xstride = lsk_gemm_xstride(p.K);
+    const int M = p.M;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
+
+    // ---- fill the weight ring before touching the activations: HBM latency hides the prologue ----
+    u32x4 ring[LSK_SPW];
+    UnitInfo cur = lsk_unit_info(0, units, ntl, ksteps, tile0, w, lane);
+#pragma unroll
+    for (int s = 0; s < LSK_SPW; ++s) {
+        const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
+        ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
+    }
+
+    // ---- activation prologue: RMSNorm statistics (fp32, fixed order), then stage K-chunk 0 ----
+    if (PRO == PRO_RMS) {
+        for (int r = 0; r < M; ++r) {
+            float ss = 0.f;
+            for (int k0 = tid * 8; k0 < p.K; k0 += LSK_KC_ELEMS) {
+                const bf16x8 v = *(const bf16x8*)(p.x + (size_t)r * p.ldx + k0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss = fmaf(f, f, ss); }
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red[r * LSK_WAVES + w] = ss;
+        }
+        __syncthreads();
+        if (tid < M) {
+            float t = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < LSK_WAVES; ++ww) t += red[tid * LSK_WAVES + ww];
+            inv[tid] = 1.0f / sqrtf(t / (float)p.K + p.eps);
+        }
+        __syncthreads();
+    }
+    lsk_stage_chunk<PRO>(p, xs, xstride, inv, 0, cur.steps_c, tid);
+    __syncthreads();
+
+    const int arow = min(lane & 15, M - 1);
+    const unsigned char* xa = xs + (size_t)arow * xstride + (lane >> 4) * 16;
+
+    f32x4 own0 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 own1 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int u = 0; u < units; ++u) {
+        const UnitInfo nxt = lsk_unit_info(u + 1, units, ntl, ksteps, tile0, w, lane);
+        if (nchunks > 1 && cur.tl == 0 && u > 0) {
+            // every wave passed the previous unit's barrier => nobody still reads the old chunk
+            lsk_stage_chunk<PRO>(p, xs, xstride, inv, cur.c, cur.steps_c, tid);
+            __syncthreads();
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < LSK_SPW; ++s) {
+            const int ksl = min(cur.ks0 + s, cur.steps_c - 1);
+            const bf16x8 a = *(const bf16x8*)(xa + ksl * 64);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, ring[s]), acc, 0, 0, 0);
+            const unsigned off = (s < nxt.nvalid) ? nxt.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
+            ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
+        }
+        float* sl = slab + ((u & 1) * LSK_WAVES + w) * 256;
+        *(f32x4*)(sl + lane * 4) = acc;
+        __syncthreads();
+        const int owner = (EPI == EPI_SWIGLU) ? (cur.tl >> 1) : cur.tl;
+        if (w == owner) {
+            const float* sb = slab + (u & 1) * LSK_WAVES * 256 + lane * 4;
+            f32x4 t = *(const f32x4*)sb;
+#pragma unroll
+            for (int ww = 1; ww < LSK_WAVES; ++ww) t += *(const f32x4*)(sb + ww * 256);
+            if (EPI == EPI_SWIGLU && (cur.tl & 1)) own1 += t; else own0 += t;
+        }
+        cur = nxt;
+    }
+
+    // ---- epilogue: owner wave `ow` holds tile (tile0 + ow) [pair ow for SWIGLU] in C layout ----
+    const int c16 = lane & 15;
+    const int rg = lane >> 4;
+    const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : ntl;
+    const bool is_owner = w < n_owned;
+
+    if (EPI == EPI_F32) {
+        if (is_owner) {
+            const int n = (tile0 + w) * 16 + c16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rg * 4 + i;
+                if (row < M && n < p.N) p.y[(size_t)row * p.N + n] = own0[i];
+            }
+        }
+    } else if (EPI == EPI_RESID) {
+        if (is_owner) {
+            const int n = (tile0 + w) * 16 + c16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rg * 4 + i;
+                if (row < M && n < p.N) {
+                    bf16_t* hp = p.h + (size_t)row * p.ldh + n;
+                    *hp = f2bf(bf2f(*hp) + rbf(own0[i]));           // residual + Linear(...) in model dtype
+                }
+            }
+        }
+    } else if (EPI == EPI_SWIGLU) {
+        if (is_owner) {
+            const int n = ((tile0 >> 1) + w) * 16 + c16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rg * 4 + i;
+                if (row < M && n < (p.N >> 1)) {
+                    const float g = rbf(own0[i]);                    // gate_proj(x)
+                    const float uu = rbf(own1[i]);                   // up_proj(x)
+                    const float s = rbf(g / (1.0f + expf(-g)));      // silu in fp32, one rounding
+                    p.act[(size_t)row * p.ldact + n] = f2bf(s * uu);
+                }
+            }
+        }
+    } else if (EPI == EPI_QKV) {
+        if (is_owner) {
+            const int hd = p.head_dim;
+            const int tph = hd >> 4;
+            const int T = tile0 + w;
+            const int nq_t = p.n_heads * tph;
+            const int nk_t = p.n_kv * tph;
+            const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);
+            const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
+            const int head = TT / tph;
+            const int tt = TT - head * tph;
+            const int base_pos = *p.kv_len + p.pos_off;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rg * 4 + i;
+                const int pos = base_pos + min(row, M - 1);
+                float v = rbf(own0[i]);
+                int feat;
+                if (kind != 2) {
+                    const float partner = __shfl_xor(v, 8, 64);
+                    const int j = tt * 8 + (c16 & 7);
+                    const float cs = bf2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
+                    const float sn = bf2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
+                    const float a = rbf(v * cs);                               // q * cos
+                    const float b = rbf((c16 < 8 ? -partner : partner) * sn);  // rotate_half(q) * sin
+                    v = rbf(a + b);
+                    feat = (c16 < 8) ? j : j + (hd >> 1);
+                } else {
+                    feat = tt * 16 + c16;
+                }
+                if (row < M) {
+                    if (kind == 0) {
+                        p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2bf(v);
+                    } else {
+                        const int page = p.block_table[pos / p.page_size];
+                        const int slot = pos % p.page_size;
+                        bf16_t* pool = (kind == 1) ? p.kpool : p.vpool;
+                        pool[(((size_t)page * p.n_kv + head) * p.page_size + slot) * hd + feat] = f2bf(v);
+                    }
+                }
+            }
+        }
+    } else if (EPI == EPI_HEAD) {
+        float* best_v = (float*)(smem + LSK_LDS_BESTV);
+        int* best_i = (int*)(smem + LSK_LDS_BESTI);
+        if (is_owner) {
+            const int n = (tile0 + w) * 16 + c16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rg * 4 + i;
+                float v = rbf(own0[i]);                              // logits in model dtype
+                if (p.logits != nullptr && row < M && n < p.N) p.logits[(size_t)row * p.ld_logits + n] = v;
+                int idx = n;
+                if (n >= p.N) { v = -INFINITY; idx = 0x7fffffff; }
+                // argmax over the tile's 16 columns, first (lowest) index wins ties like torch.argmax
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(v, o, 64);
+                    const int oi = __shfl_xor(idx, o, 64);
+                    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+                }
+                if (c16 == 0) { best_v[w * 16 + row] = v; best_i[w * 16 + row] = idx; }
+            }
+        }
+        __syncthreads();
+        if (tid < M) {
+            float v = best_v[tid];
+            int idx = best_i[tid];
+            for (int t = 1; t < n_owned; ++t) {
+                const float ov = best_v[t * 16 + tid];
+                const int oi = best_i[t * 16 + tid];
+                if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+            }
+            p.part_val[blockIdx.x * 16 + tid] = v;
+            p.part_idx[blockIdx.x * 16 + tid] = idx;
+        }
+    }
+}

@@ -1,0 +1,293 @@
+"""Host side of the MI355X self-speculative decoding engine.
+
+``HipEngine`` borrows a ``transformers.LlamaForCausalLM`` (the object the reference's strategies are
+handed, reference self_speculation/generator_base.py:52-62), re-lays its projection weights once into
+the MFMA-fragment layout the HIP kernels stream, owns the paged KV pool and the workspace, and exposes
+the C-ABI entry points of ``include/layerskip_hip.h`` as methods.
+
+PyTorch is used for storage and stream handles only: every tensor here is a buffer whose
+``data_ptr()`` is passed to liblayerskip_hip.so.  No torch op computes anything on the decoding path.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import LskConfig, LskStepResult, check
+
+BUF_STEP = 0   # 16-row step buffer (draft rows / verify block)
+BUF_BULK = 1   # prompt rows (prefill), doubles as the exit_query_cache of the first step
+
+
+@dataclass
+class StepResult:
+    """What ``single_step_speculation`` returns in the reference (SSG:223-229) plus the tokens."""
+    num_matches: int
+    num_drafts: int
+    next_token: int
+    kv_len: int
+    emitted: List[int]
+    draft_tokens: List[int]
+    verified_tokens: List[int]
+
+
+def _round_up(v: int, a: int) -> int:
+    return (v + a - 1) // a * a
+
+
+def _i32_array(values: Sequence[int]):
+    arr = (ctypes.c_int32 * max(1, len(values)))()
+    for i, v in enumerate(values):
+        arr[i] = int(v)
+    return arr
+
+
+class HipEngine:
+    """One engine per (model, device).  Not re-entrant; one caller thread (like the reference)."""
+
+    def __init__(self, model, max_ctx: int = 2048, max_prompt: int = 1024, page_size: int = 128,
+                 target_wgs: int = 0):
+        self.lib = _lib.load()
+        cfg = model.config
+        weight = model.model.embed_tokens.weight
+        if weight.device.type != "cuda":
+            raise _lib.LskError("HipEngine needs the model on a HIP device (model.to('cuda')); there is no CPU path")
+        if weight.dtype != torch.bfloat16:
+            raise _lib.LskError(f"HipEngine computes in bf16; model dtype is {weight.dtype}")
+        if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
+            raise _lib.LskError("biased projections are not supported")
+        self.model = model          # keeps the borrowed weights alive
+        self.device = weight.device
+        self.num_layers = cfg.num_hidden_layers
+        self.hidden = cfg.hidden_size
+        self.intermediate = cfg.intermediate_size
+        self.n_heads = cfg.num_attention_heads
+        self.n_kv_heads = cfg.num_key_value_heads
+        self.head_dim = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        self.vocab = cfg.vocab_size
+        self.page_size = page_size
+        self.target_wgs = target_wgs
+        self._handle = ctypes.c_void_p(None)
+        self._packed = []           # per-layer packed buffers (kept alive)
+        self._globals = {}
+        self._buffers = {}
+        with torch.cuda.device(self.device):
+            self._pack_weights()
+            self._allocate(max_ctx, max_prompt)
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _packed_buffer(self, n_rows: int, k: int) -> torch.Tensor:
+        nbytes = ctypes.c_size_t(0)
+        check(self.lib.lsk_packed_bytes(n_rows, k, ctypes.byref(nbytes)))
+        return torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+
+    def _pack_into(self, dst: torch.Tensor, w: torch.Tensor, tile_offset: int, tile_stride: int, rope_hd: int) -> None:
+        w = w.detach()
+        if w.dtype != torch.bfloat16 or w.device != self.device:
+            raise _lib.LskError("all projection weights must be bf16 on the engine's device")
+        if w.stride(1) != 1:
+            w = w.contiguous()
+        check(self.lib.lsk_pack_linear(w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), dst.data_ptr(),
+                                       tile_offset, tile_stride, rope_hd, self._stream))
+
+    def _pack_weights(self) -> None:
+        m = self.model
+        hd, H, I = self.head_dim, self.hidden, self.intermediate
+        qdim, kvdim = self.n_heads * hd, self.n_kv_heads * hd
+        for layer in m.model.layers:
+            a, mlp = layer.self_attn, layer.mlp
+            wqkv = self._packed_buffer(qdim + 2 * kvdim, H)
+            self._pack_into(wqkv, a.q_proj.weight, 0, 1, hd)
+            self._pack_into(wqkv, a.k_proj.weight, qdim // 16, 1, hd)
+            self._pack_into(wqkv, a.v_proj.weight, (qdim + kvdim) // 16, 1, 0)
+            wo = self._packed_buffer(H, qdim)
+            self._pack_into(wo, a.o_proj.weight, 0, 1, 0)
+            wgu = self._packed_buffer(2 * I, H)
+            self._pack_into(wgu, mlp.gate_proj.weight, 0, 2, 0)
+            self._pack_into(wgu, mlp.up_proj.weight, 1, 2, 0)
+            wdown = self._packed_buffer(H, I)
+            self._pack_into(wdown, mlp.down_proj.weight, 0, 1, 0)
+            n1 = layer.input_layernorm.weight.detach().contiguous()
+            n2 = layer.post_attention_layernorm.weight.detach().contiguous()
+            self._packed.append((wqkv, wo, wgu, wdown, n1, n2))
+        head = self._packed_buffer(self.vocab, H)
+        self._pack_into(head, m.lm_head.weight, 0, 1, 0)
+        self._globals["lm_head"] = head
+        self._globals["embed"] = m.model.embed_tokens.weight.detach().contiguous()
+        self._globals["final_norm"] = m.model.norm.weight.detach().contiguous()
+        torch.cuda.synchronize(self.device)
+
+    def _rope_tables(self, length: int):
+        """cos/sin exactly as LlamaRotaryEmbedding.forward computes them on CPU (fp32 -> bf16)."""
+        rot = self.model.model.rotary_emb
+        inv_freq = rot.inv_freq.detach().to("cpu", torch.float32)
+        scaling = float(rot.attention_scaling)
+        pos = torch.arange(length, dtype=torch.float32)
+        freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]   # [length, d/2]
+        cos = (freqs.cos() * scaling).to(torch.bfloat16)
+        sin = (freqs.sin() * scaling).to(torch.bfloat16)
+        return cos.contiguous().to(self.device), sin.contiguous().to(self.device)
+
+    # ------------------------------------------------------------------ buffers / C engine
+    def _allocate(self, max_ctx: int, max_prompt: int) -> None:
+        if self._handle:
+            check(self.lib.lsk_engine_destroy(self._handle))
+            self._handle = ctypes.c_void_p(None)
+        self.max_ctx = _round_up(max(max_ctx, self.page_size), self.page_size)
+        self.max_prompt = max(16, int(max_prompt))
+        rms_eps = float(self.model.config.rms_norm_eps)
+        self.cfg = LskConfig(self.num_layers, self.hidden, self.intermediate, self.n_heads, self.n_kv_heads,
+                             self.head_dim, self.vocab, rms_eps, self.max_ctx, self.page_size,
+                             self.max_prompt, self.target_wgs)
+        ws, kv = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(self.lib.lsk_workspace_bytes(ctypes.byref(self.cfg), ctypes.byref(ws)))
+        check(self.lib.lsk_kv_pool_bytes(ctypes.byref(self.cfg), ctypes.byref(kv)))
+        self._buffers["ws"] = torch.zeros(ws.value, dtype=torch.uint8, device=self.device)
+        self._buffers["kv"] = torch.zeros(kv.value, dtype=torch.uint8, device=self.device)
+        cos, sin = self._rope_tables(self.max_ctx)
+        self._buffers["cos"], self._buffers["sin"] = cos, sin
+        torch.cuda.synchronize(self.device)
+        handle = ctypes.c_void_p(None)
+        check(self.lib.lsk_engine_create(ctypes.byref(self.cfg), self._buffers["ws"].data_ptr(), ws.value,
+                                         self._buffers["kv"].data_ptr(), kv.value, ctypes.byref(handle)))
+        self._handle = handle
+        for i, (wqkv, wo, wgu, wdown, n1, n2) in enumerate(self._packed):
+            check(self.lib.lsk_engine_set_layer(handle, i, wqkv.data_ptr(), wo.data_ptr(), wgu.data_ptr(),
+                                                wdown.data_ptr(), n1.data_ptr(), n2.data_ptr()))
+        g = self._globals
+        check(self.lib.lsk_engine_set_globals(handle, g["embed"].data_ptr(), g["final_norm"].data_ptr(),
+                                              g["lm_head"].data_ptr(), cos.data_ptr(), sin.data_ptr(), self.max_ctx))
+
+    def ensure_capacity(self, total_tokens: int, prompt_len: int) -> None:
+        """Grow the KV pool / prompt buffer if a request needs more (context is lost)."""
+        if total_tokens > self.max_ctx or prompt_len > self.max_prompt:
+            with torch.cuda.device(self.device):
+                self._allocate(max(total_tokens, self.max_ctx), max(prompt_len, self.max_prompt))
+
+    def close(self) -> None:
+        if self._handle:
+            self.lib.lsk_engine_destroy(self._handle)
+            self._handle = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state
+    def reset(self) -> None:
+        check(self.lib.lsk_engine_reset(self._handle, self._stream))
+
+    @property
+    def kv_len(self) -> int:
+        v = ctypes.c_int32(0)
+        check(self.lib.lsk_engine_get_kv_len(self._handle, ctypes.byref(v)))
+        return v.value
+
+    def set_kv_len(self, kv_len: int) -> None:
+        check(self.lib.lsk_engine_set_kv_len(self._handle, int(kv_len), self._stream))
+
+    def set_block_table(self, table: Sequence[int]) -> None:
+        arr = _i32_array(table)
+        check(self.lib.lsk_engine_set_block_table(self._handle, arr, len(table), self._stream))
+
+    # ------------------------------------------------------------------ fused fast paths
+    def spec_step(self, input_ids: Sequence[int], num_speculations: int, exit_layer: int,
+                  eos_token_ids: Sequence[int]) -> StepResult:
+        ids = _i32_array(input_ids)
+        eos = [t for t in eos_token_ids if 0 <= t < self.vocab][: _lib.LSK_MAX_EOS]
+        eos_arr = _i32_array(eos)
+        res = LskStepResult()
+        check(self.lib.lsk_spec_step(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer),
+                                     eos_arr, len(eos), ctypes.byref(res), self._stream))
+        n, s = res.num_matches, int(num_speculations)
+        return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
+                          list(res.draft_tokens[:s]), list(res.verified_tokens[: s + 1]))
+
+    def ar_step(self, input_ids: Sequence[int], layer_end: Optional[int] = None) -> int:
+        ids = _i32_array(input_ids)
+        tok = ctypes.c_int32(0)
+        check(self.lib.lsk_ar_step(self._handle, ids, len(input_ids), int(layer_end or self.num_layers),
+                                   ctypes.byref(tok), self._stream))
+        return tok.value
+
+    # ------------------------------------------------------------------ building blocks
+    def embed_rows(self, ids: Sequence[int], buffer: int, row_base: int) -> None:
+        arr = _i32_array(ids)
+        check(self.lib.lsk_embed_rows(self._handle, arr, len(ids), buffer, row_base, self._stream))
+
+    def run_layers(self, buffer: int, row_base: int, m: int, pos_offset: int, layer_begin: int, layer_end: int) -> None:
+        check(self.lib.lsk_run_layers(self._handle, buffer, row_base, m, pos_offset, layer_begin, layer_end, self._stream))
+
+    def run_layers_chunked(self, buffer: int, row_base: int, n: int, pos_offset: int, layer_begin: int, layer_end: int) -> None:
+        for r0 in range(0, n, _lib.LSK_MAX_ROWS):
+            m = min(_lib.LSK_MAX_ROWS, n - r0)
+            self.run_layers(buffer, row_base + r0, m, pos_offset + r0, layer_begin, layer_end)
+
+    def run_head(self, buffer: int, row_base: int, m: int, logits: Optional[torch.Tensor] = None,
+                 want_tokens: bool = True) -> Optional[List[int]]:
+        """logits: optional fp32 CUDA tensor [m, >=vocab] that receives the (bf16-rounded) logits."""
+        ptr, ld = None, 0
+        if logits is not None:
+            if logits.dtype != torch.float32 or logits.device != self.device or logits.stride(-1) != 1:
+                raise _lib.LskError("logits buffer must be a contiguous fp32 tensor on the engine device")
+            ptr, ld = logits.data_ptr(), logits.stride(0)
+        toks = (ctypes.c_int32 * m)() if want_tokens else None
+        check(self.lib.lsk_run_head(self._handle, buffer, row_base, m, ptr, ld, toks, self._stream))
+        return list(toks) if want_tokens else None
+
+    def read_rows(self, buffer: int, row_base: int, m: int) -> torch.Tensor:
+        out = torch.empty(m, self.hidden, dtype=torch.bfloat16, device=self.device)
+        check(self.lib.lsk_read_rows(self._handle, buffer, row_base, m, out.data_ptr(), self._stream))
+        return out
+
+    def write_rows(self, buffer: int, row_base: int, rows: torch.Tensor) -> None:
+        rows = rows.to(self.device, torch.bfloat16).contiguous()
+        check(self.lib.lsk_write_rows(self._handle, buffer, row_base, rows.shape[0], rows.data_ptr(), self._stream))
+
+    # ------------------------------------------------------------------ measurement hooks
+    def time_gateup(self, layer: int, m: int, iters: int) -> float:
+        ms = ctypes.c_float(0.0)
+        check(self.lib.lsk_time_gateup(self._handle, layer, m, iters, ctypes.byref(ms), self._stream))
+        return ms.value
+
+    def set_profile(self, enable: bool) -> None:
+        check(self.lib.lsk_engine_set_profile(self._handle, 1 if enable else 0))
+
+    def get_profile(self):
+        ms, n = ctypes.c_float(0.0), ctypes.c_int32(0)
+        check(self.lib.lsk_engine_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    # bytes one launch of each projection streams from HBM (algorithmic: the packed weights once)
+    def projection_bytes(self) -> dict:
+        hd = self.head_dim
+        qdim, kvdim = self.n_heads * hd, self.n_kv_heads * hd
+        return {
+            "qkv": 2 * (qdim + 2 * kvdim) * self.hidden,
+            "o": 2 * self.hidden * qdim,
+            "gate_up": 2 * 2 * self.intermediate * self.hidden,
+            "down": 2 * self.hidden * self.intermediate,
+            "lm_head": 2 * self.vocab * self.hidden,
+        }
+
+
+_ENGINE_ATTR = "_layerskip_hip_engine"
+
+
+def get_engine(model, **kwargs) -> HipEngine:
+    """The engine bound to ``model`` (built lazily on first use, reused across calls)."""
+    eng = getattr(model, _ENGINE_ATTR, None)
+    if eng is None:
+        eng = HipEngine(model, **kwargs)
+        object.__setattr__(model, _ENGINE_ATTR, eng)
+    return eng

@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE.  Generates tests/golden/*.json from the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/make_golden.py            # regenerate every fixture
+    python oracle/make_golden.py --check    # re-run and compare with the committed files
+
+For every synthetic case it
+  1. builds the deterministic checkpoint (layerskip_amd/synthetic.py, CPU generator);
+  2. runs the reference's own ``SelfSpeculativeGenerationStrategy`` and
+     ``AutoRegressiveGenerationStrategy`` (greedy) through oracle/ref_shim.py, in bf16 (the
+     dtype BASELINE.json quotes) and in fp32 on the same bf16-valued weights;
+  3. runs the restatement oracle/llama_oracle.py on the same weights and REQUIRES identical
+     token ids, per-step (num_drafts, num_matches) and bit-identical teacher-forced logits
+     -- this is what pins the restatement to the reference;
+  4. writes token ids, acceptance counters, per-token top-2 margins and a few logits rows.
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from layerskip_amd import synthetic  # noqa: E402
+from oracle import llama_oracle as lo  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+CASES = {
+    "tiny_mha_s0": synthetic.SyntheticCase("tiny-mha", seed=0, prompt_len=24, prompt_seed=0, max_steps=48),
+    "tiny_mha_s1": synthetic.SyntheticCase("tiny-mha", seed=1, prompt_len=33, prompt_seed=1, max_steps=40,
+                                           num_speculations=6, late_damping=0.05),
+    "tiny_gqa_s0": synthetic.SyntheticCase("tiny-gqa", seed=0, prompt_len=37, prompt_seed=2, max_steps=40),
+    "tiny_gqa_long": synthetic.SyntheticCase("tiny-gqa", seed=3, prompt_len=300, prompt_seed=3, max_steps=24,
+                                             num_speculations=12),
+    "tiny_d64_s0": synthetic.SyntheticCase("tiny-d64", seed=0, prompt_len=19, prompt_seed=4, max_steps=32),
+    "small_wide_s0": synthetic.SyntheticCase("small-wide", seed=0, prompt_len=20, prompt_seed=5, max_steps=12),
+}
+# EOS cases are derived: the eos id is the k-th token of the base case's bf16 output.
+EOS_CASES = {"tiny_mha_s0_eos": ("tiny_mha_s0", 17), "tiny_gqa_s0_eos": ("tiny_gqa_s0", 9)}
+
+
+def run_reference(ref, model, prompt, eos, case, strategy):
+    gb = ref.generator_base
+    cfg = gb.GenerationConfig(max_steps=case.max_steps, exit_layer=case.exit_layer,
+                              num_speculations=case.num_speculations, sample=False,
+                              generation_strategy=strategy)
+    if strategy == "self_speculative":
+        strat = ref.self_speculation_generator.SelfSpeculativeGenerationStrategy()
+    else:
+        strat = ref.autoregressive_generator.AutoRegressiveGenerationStrategy()
+        cfg.exit_layer = -1
+    with torch.inference_mode():
+        return strat.generate_token_ids(model=model, input_ids=list(prompt), eos_token_ids=list(eos),
+                                        generation_config=cfg, logits_processors=None,
+                                        stopping_criteria=None, streamer=None)
+
+
+def topk_rows(logits: torch.Tensor, rows, k=8):
+    out = []
+    for r in rows:
+        vals, idx = torch.topk(logits[r].float(), k)
+        out.append({"row": int(r), "idx": idx.tolist(), "val": [float(v) for v in vals]})
+    return out
+
+
+def one_dtype(ref, model_bf16, case, prompt, eos, dtype):
+    model = copy.deepcopy(model_bf16).to(dtype)
+    ref_shim.patch_model(model)
+    ref_spec = run_reference(ref, model, prompt, eos, case, "self_speculative")
+    ref_ar = run_reference(ref, model, prompt, eos, case, "autoregressive")
+    om = lo.OracleModel.from_hf(model)
+    with torch.inference_mode():
+        mine_spec = lo.self_speculative_generate(om, list(prompt), list(eos), case.max_steps, case.exit_layer,
+                                                 case.num_speculations)
+        mine_ar = lo.autoregressive_generate(om, list(prompt), list(eos), case.max_steps)
+        # --- pin the restatement to the reference ---
+        assert mine_spec.predicted_tokens == ref_spec.predicted_tokens, "restated spec ids != reference"
+        assert abs(mine_spec.acceptance_rate - ref_spec.acceptance_rate) == 0.0, "acceptance differs"
+        assert mine_ar.predicted_tokens == ref_ar.predicted_tokens, "restated AR ids != reference"
+        seq = list(prompt) + ref_spec.predicted_tokens
+        ref_logits = ref.llama_model_utils.forward(model, torch.tensor([seq]), None).logits[0]
+        my_logits = lo.teacher_forced_logits(om, seq)
+        assert torch.equal(ref_logits, my_logits), "teacher-forced logits are not bit-identical"
+    rows = sorted(set(r for r in [len(prompt) - 1, len(prompt), len(seq) // 2, len(seq) - 1] if r < len(seq)))
+    return {
+        "spec_tokens": ref_spec.predicted_tokens,
+        "acceptance_rate": ref_spec.acceptance_rate,
+        "steps": [[s.num_drafts, s.num_matches] for s in mine_spec.steps],
+        "spec_margins": [round(m, 6) for m in mine_spec.margins],
+        "ar_tokens": ref_ar.predicted_tokens,
+        "ar_margins": [round(m, 6) for m in mine_ar.margins],
+        "spec_equals_ar": ref_spec.predicted_tokens == ref_ar.predicted_tokens,
+        "logits_topk": topk_rows(my_logits, rows),
+    }
+
+
+def build_case(ref, name, case, eos=None):
+    case = case.resolved()
+    cfg = synthetic.make_config(case.shape)
+    model = synthetic.build_model(cfg, seed=case.seed, exit_layer=case.exit_layer, late_damping=case.late_damping,
+                                  dtype=torch.bfloat16, device="cpu")
+    prompt = synthetic.make_prompt(cfg.vocab_size, case.prompt_len, case.prompt_seed)
+    eos = [cfg.vocab_size] if eos is None else eos   # unreachable id -> always max_steps tokens
+    rec = {
+        "name": name, "shape": case.shape, "seed": case.seed, "late_damping": case.late_damping,
+        "exit_layer": case.exit_layer, "num_speculations": case.num_speculations,
+        "prompt_len": case.prompt_len, "prompt_seed": case.prompt_seed, "max_steps": case.max_steps,
+        "eos_token_ids": eos, "prompt": prompt,
+        "attn_implementation": model.config._attn_implementation,
+        "torch": torch.__version__,
+    }
+    import transformers
+    rec["transformers"] = transformers.__version__
+    for dname, dtype in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        rec[dname] = one_dtype(ref, model, case, prompt, eos, dtype)
+        print(f"  {name} {dname}: {len(rec[dname]['spec_tokens'])} tokens, acceptance "
+              f"{rec[dname]['acceptance_rate']:.3f}, spec==ar {rec[dname]['spec_equals_ar']}, "
+              f"min margin {min(rec[dname]['spec_margins'] or [0]):.4f}")
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    ref = ref_shim.load_reference()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    records = {}
+    for name, case in CASES.items():
+        if args.only and args.only not in name:
+            continue
+        records[name] = build_case(ref, name, case)
+    for name, (base, k) in EOS_CASES.items():
+        if args.only and args.only not in name:
+            continue
+        if base not in records:
+            records[base] = build_case(ref, base, CASES[base])
+        eos_id = records[base]["bf16"]["spec_tokens"][k]
+        records[name] = build_case(ref, name, CASES[base], eos=[eos_id])
+    bad = 0
+    for name, rec in records.items():
+        path = os.path.join(GOLDEN_DIR, name + ".json")
+        if args.check:
+            with open(path) as f:
+                old = json.load(f)
+            same = all(old[d]["spec_tokens"] == rec[d]["spec_tokens"] and old[d]["ar_tokens"] == rec[d]["ar_tokens"]
+                       and old[d]["steps"] == rec[d]["steps"] for d in ("bf16", "fp32"))
+            print(("OK   " if same else "DIFF ") + name)
+            bad += 0 if same else 1
+        else:
+            with open(path, "w") as f:
+                json.dump(rec, f)
+            print("wrote", path)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

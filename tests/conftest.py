@@ -1,0 +1,44 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json"))
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN_DIR, name + ".json")) as f:
+        return json.load(f)
+
+
+def build_case_model(rec, device="cpu"):
+    """The deterministic checkpoint a golden record was generated from."""
+    import torch
+    from layerskip_amd import synthetic
+    cfg = synthetic.make_config(rec["shape"])
+    model = synthetic.build_model(cfg, seed=rec["seed"], exit_layer=rec["exit_layer"],
+                                  late_damping=rec["late_damping"], dtype=torch.bfloat16, device="cpu")
+    if device != "cpu":
+        model = model.to(device)
+    return model
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")

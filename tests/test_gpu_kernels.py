@@ -1,0 +1,122 @@
+"""Single-kernel parity on the GPU: every HIP kernel against a plain fp32 torch statement of the op."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from layerskip_amd import _lib
+    return _lib.load(), _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pack(w, rope_hd=0):
+    lib, L = _lib()
+    n, k = w.shape
+    nbytes = ctypes.c_size_t(0)
+    L.check(lib.lsk_packed_bytes(n, k, ctypes.byref(nbytes)))
+    dst = torch.zeros(nbytes.value, dtype=torch.uint8, device=w.device)
+    L.check(lib.lsk_pack_linear(w.data_ptr(), n, k, w.stride(0), dst.data_ptr(), 0, 1, rope_hd, _stream()))
+    return dst
+
+
+def _gemm(x, wp, n, norm_w=None, eps=1e-5, target_wgs=0):
+    lib, L = _lib()
+    m, k = x.shape
+    y = torch.full((m, n), float("nan"), dtype=torch.float32, device=x.device)
+    L.check(lib.lsk_test_gemm(x.data_ptr(), m, k, wp.data_ptr(), n, None if norm_w is None else norm_w.data_ptr(),
+                              eps, y.data_ptr(), target_wgs, _stream()))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 256, 64), (7, 4096, 512), (16, 4096, 1040), (3, 704, 256), (13, 11008, 320),
+                                   (5, 8192, 48), (16, 1408, 1000)])
+def test_skinny_gemm_matches_fp32(gpu_device, m, k, n):
+    """A = asymmetric random (transpose / row-swap detecting); fp32 accumulate => tight tolerance."""
+    g = torch.Generator().manual_seed(m * 1000 + k + n)
+    x = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).to(gpu_device)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(gpu_device)
+    y = _gemm(x, _pack(w), n)
+    ref = x.float() @ w.float().t()
+    assert torch.isfinite(y).all()
+    err = (y - ref).abs().max().item()
+    assert err <= 1e-3, f"max abs err {err}"
+
+
+def test_skinny_gemm_identity_weight(gpu_device):
+    """W = I picks x back out exactly: catches any fragment-layout permutation."""
+    k = n = 256
+    x = torch.arange(4 * k, dtype=torch.float32).reshape(4, k).div(64.0).to(torch.bfloat16).to(gpu_device)
+    w = torch.eye(n, k, dtype=torch.bfloat16, device=gpu_device)
+    y = _gemm(x, _pack(w), n)
+    assert torch.equal(y, x.float())
+
+
+def test_skinny_gemm_rmsnorm_prologue(gpu_device):
+    g = torch.Generator().manual_seed(7)
+    m, k, n = 6, 4096, 256
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(gpu_device)
+    w = (torch.randn(n, k, generator=g) * 0.02).to(torch.bfloat16).to(gpu_device)
+    nw = (1 + 0.1 * torch.randn(k, generator=g)).to(torch.bfloat16).to(gpu_device)
+    eps = 1e-5
+    y = _gemm(x, _pack(w), n, norm_w=nw, eps=eps)
+    x32 = x.float()
+    xn = (x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + eps)).to(torch.bfloat16)
+    xn = (nw * xn)                      # bf16 * bf16 -> bf16, as LlamaRMSNorm does
+    ref = xn.float() @ w.float().t()
+    # the normalised activations may differ by one bf16 ulp where fp32 statistics round differently
+    err = (y - ref).abs().max().item()
+    assert err <= 2e-2, err
+    frac_exact = ((y - ref).abs() <= 1e-3).float().mean().item()
+    assert frac_exact > 0.9, frac_exact
+
+
+def test_skinny_gemm_row_invariance(gpu_device):
+    """Row r of an M-row pass is bit-identical to the same row in a 1-row pass (and any grid size)."""
+    g = torch.Generator().manual_seed(11)
+    k, n = 11008, 512
+    x = torch.randn(9, k, generator=g).to(torch.bfloat16).to(gpu_device)
+    w = (torch.randn(n, k, generator=g) * 0.02).to(torch.bfloat16).to(gpu_device)
+    wp = _pack(w)
+    y9 = _gemm(x, wp, n)
+    for r in (0, 4, 8):
+        y1 = _gemm(x[r:r + 1].contiguous(), wp, n)
+        assert torch.equal(y1[0], y9[r])
+    y9b = _gemm(x, wp, n, target_wgs=7)
+    assert torch.equal(y9, y9b)
+
+
+@pytest.mark.parametrize("drafts,verified,eos,expect", [
+    ([5, 6, 7, 8], [5, 6, 9, 8, 1], [], (2, 4)),
+    ([5, 6, 7, 8], [5, 6, 7, 8, 1], [], (4, 4)),
+    ([5, 6, 7, 8], [4, 6, 7, 8, 1], [], (0, 4)),
+    ([], [3], [], (0, 0)),
+    ([5, 2, 7, 8], [5, 2, 7, 8, 1], [2], (2, 2)),     # drafted EOS ends the draft (SSG:146-148)
+    ([5, 2, 7, 8], [9, 2, 7, 8, 1], [2, 11], (0, 2)),
+    (list(range(15)), list(range(15)) + [99], [], (15, 15)),
+])
+def test_accept_kernel(gpu_device, drafts, verified, eos, expect):
+    lib, L = _lib()
+    d = torch.tensor(drafts + [0], dtype=torch.int32, device=gpu_device)
+    v = torch.tensor(verified, dtype=torch.int32, device=gpu_device)
+    e = torch.tensor(eos + [0], dtype=torch.int32, device=gpu_device)
+    res = torch.full((32,), -1, dtype=torch.int32, device=gpu_device)
+    L.check(lib.lsk_test_accept(d.data_ptr(), v.data_ptr(), len(drafts), e.data_ptr(), len(eos), res.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    r = res.tolist()
+    n, td = expect
+    assert (r[0], r[1]) == (n, td)
+    assert r[2] == verified[n]
+    assert r[4:4 + n + 1] == drafts[:n] + [verified[n]]
+    # the reference expression, SSG:186-190
+    dt = torch.tensor([drafts[:td]])
+    vt = torch.tensor([verified[:td + 1]])
+    ref_n = int(((~(dt == vt[:, :-1])).cumsum(dim=-1) < 1).sum().item())
+    assert ref_n == n
