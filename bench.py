@@ -1,0 +1,235 @@
+"""Headline benchmark: decoded tokens/sec + acceptance rate of self-speculative decoding
+(llama2-7B shape, exit_layer=8, num_speculations=6, 512-token prompts, 512 new tokens, bf16, greedy)
+through the HIP engine, with the decode-bandwidth roofline and a CPU baseline beside it.
+
+    python bench.py --gpus 1 --steps 4 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one `generate_token_ids` call: one synthetic 512-token prompt -> `max_steps` new tokens
+(reference benchmark.py:186-200 / generator_base.py:107-130).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from layerskip_amd import GenerationConfig, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="llama2-7B", choices=sorted(synthetic.SHAPES))
+    ap.add_argument("--prompt-len", type=int, default=512)
+    ap.add_argument("--max-steps", type=int, default=512)
+    ap.add_argument("--exit-layer", type=int, default=None)
+    ap.add_argument("--num-speculations", type=int, default=None)
+    ap.add_argument("--late-damping", type=float, default=0.03)
+    ap.add_argument("--strategy", default="self_speculative", choices=["self_speculative", "autoregressive"])
+    ap.add_argument("--target-wgs", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-new-tokens", type=int, default=16)
+    ap.add_argument("--cpu-prompt-len", type=int, default=64)
+    return ap.parse_args()
+
+
+def step_bytes(cfg, exit_layer, prompt_len, trace):
+    """ALGORITHMIC bytes of a whole generation (SURVEY.md 8d / BASELINE.md section 4): every weight
+    and every live KV byte once per forward call that needs it.  trace = [(kv_len_before, P, T_d, n)]."""
+    H, I, V, L = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers
+    hd = getattr(cfg, "head_dim", None) or H // cfg.num_attention_heads
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    w_layer = 2 * (2 * H * nh * hd + 2 * H * nkv * hd + 3 * H * I + 2 * H)
+    w_head = 2 * V * H
+    kv_tok = 2 * nkv * hd * 2          # K and V bytes per token per layer
+    total = 0
+    E = exit_layer
+    for (c, p, td, n) in trace:
+        ctx = c + p
+        for j in range(td):            # draft calls: E layers + head, KV of the early layers
+            total += E * w_layer + w_head + E * kv_tok * (ctx + j)
+        # verify: all layers + head once (prompt rows of the first step reuse the same weight pass)
+        total += L * w_layer + w_head + L * kv_tok * (ctx + td)
+    return total
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the engine)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from layerskip_amd.engine import get_engine
+    from layerskip_amd.hip_strategies import HipAutoRegressiveGenerationStrategy, HipSelfSpeculativeGenerationStrategy
+
+    E = args.exit_layer or synthetic.default_exit_layer(args.model)
+    S = args.num_speculations or synthetic.default_num_speculations(args.model)
+    cfg = synthetic.make_config(args.model)
+    t0 = time.time()
+    model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=args.late_damping, dtype=torch.bfloat16,
+                                  device=dev, gen_device=dev)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    engine = get_engine(model, max_ctx=args.prompt_len + args.max_steps + S + 16, max_prompt=args.prompt_len,
+                        target_wgs=args.target_wgs)
+    spec = args.strategy == "self_speculative"
+    strategy = HipSelfSpeculativeGenerationStrategy() if spec else HipAutoRegressiveGenerationStrategy()
+    gen = GenerationConfig(max_steps=args.max_steps, exit_layer=E if spec else -1, num_speculations=S if spec else -1,
+                           sample=False, generation_strategy=args.strategy)
+    eos = [cfg.vocab_size]   # unreachable id: every generation runs to max_steps
+
+    def one(i):
+        # every rank decodes its own prompts (replica per GPU; see DESIGN.md "multi-GPU")
+        prompt = synthetic.make_prompt(cfg.vocab_size, args.prompt_len, 7919 * rank + i)
+        return strategy.generate_token_ids(model, prompt, eos, gen)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one(1000 + i)
+    barrier()
+    t0 = time.perf_counter()
+    results = [one(i) for i in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tokens = sum(len(r.predicted_tokens) for r in results)
+    acc = [r.acceptance_rate for r in results if r.acceptance_rate is not None]
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed, float(tokens)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        tokens = int(tsum[1].item())
+    value = tokens / elapsed
+
+    out = {
+        "metric": "decoded tokens/sec (self-speculative, greedy)" if spec else "decoded tokens/sec (autoregressive, greedy)",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "acceptance_rate": round(sum(acc) / len(acc), 4) if acc else None,
+        "config": {"workload": f"{args.model} shape, exit_layer={E}, num_speculations={S}, {args.prompt_len}-token prompt, "
+                               f"{args.max_steps} new tokens, batch 1, greedy, random-init weights (late damping {args.late_damping})",
+                   "strategy": args.strategy, "parallelism": "replica per GPU" if world > 1 else "single GPU"},
+        "model_build_s": round(build_s, 1),
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (gate/up projection): HIP events on the launch stream ----
+        pb = engine.projection_bytes()
+        engine.set_profile(True)
+        traced = one(0)
+        torch.cuda.synchronize()
+        ms, launches = engine.get_profile()
+        engine.set_profile(False)
+        back_to_back_ms = engine.time_gateup(0, 1, 64)
+        avg_ms = ms / max(1, launches)
+        achieved = pb["gate_up"] / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "kernel": "lsk_gemm_kernel<PRO_RMS,EPI_SWIGLU> (post-attn RMSNorm + gate/up + SiLU*mul)",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": pb["gate_up"], "avg_launch_ms": round(avg_ms, 5), "launches_timed": launches,
+            "back_to_back_launch_ms": round(back_to_back_ms, 5),
+        }
+        # ---- whole-path decode-bandwidth roofline from the run's own (T_d, n, ctx) ----
+        if spec:
+            trace, c, p = [], 0, args.prompt_len
+            produced = 0
+            # re-derive the per-step trace from a traced run (cheap: host bookkeeping only)
+            eng_steps = _trace_steps(strategy, model, synthetic.make_prompt(cfg.vocab_size, args.prompt_len, 0), eos, gen)
+            for (td, n) in eng_steps:
+                trace.append((c, p, td, n))
+                c, p = c + p + n, 1
+                produced += n + 1
+            total_b = step_bytes(cfg, E, args.prompt_len, trace)
+            floor_s = total_b / (HBM_PEAK_GBS * 1e9)
+            out["path_roofline"] = {"algorithmic_bytes_per_generation": total_b,
+                                    "floor_tokens_per_s_at_8TBs": round(produced / floor_s, 1),
+                                    "frac_of_floor": round((value / world) / (produced / floor_s), 4)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, cfg, model, E, S, strategy, eos)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _trace_steps(strategy, model, prompt, eos, gen):
+    """(num_drafts, num_matches) of every speculation step of one generation."""
+    steps = []
+    inner = strategy.single_step_speculation
+
+    def spy(**kw):
+        r = inner(**kw)
+        steps.append((r[4], r[3]))
+        return r
+
+    strategy.single_step_speculation = spy
+    try:
+        strategy.generate_token_ids(model, prompt, eos, gen)
+    finally:
+        del strategy.single_step_speculation
+    return steps
+
+
+def cpu_baseline(args, cfg, model, E, S, strategy, eos):
+    """The reference path on the host cores: the reference-pinned restatement (oracle/llama_oracle.py,
+    kind "port": /root/reference does not exist on the GPU box) on the SAME weights, bounded sample."""
+    from oracle import llama_oracle as lo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    om = lo.OracleModel.from_hf(model)          # copies the bf16 weights to host memory
+    copy_s = time.time() - t0
+    prompt = synthetic.make_prompt(cfg.vocab_size, args.cpu_prompt_len, 4242)
+    n_new = args.cpu_new_tokens
+    with torch.inference_mode():
+        t0 = time.time()
+        tr = lo.self_speculative_generate(om, prompt, eos, n_new, E, S)
+        cpu_s = time.time() - t0
+    gen = GenerationConfig(max_steps=n_new, exit_layer=E, num_speculations=S, sample=False,
+                           generation_strategy="self_speculative")
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    got = HipSelfSpeculativeGenerationStrategy().generate_token_ids(model, prompt, eos, gen)
+    first = next((i for i, (a, b) in enumerate(zip(got.predicted_tokens, tr.predicted_tokens)) if a != b), None)
+    return {"value": round(len(tr.predicted_tokens) / cpu_s, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 prompt of {args.cpu_prompt_len} tokens, {n_new} new tokens, same weights, bf16, "
+                      f"torch CPU {torch.get_num_threads()} threads, {cpu_s:.1f} s (weights D2H {copy_s:.1f} s not counted)",
+            "acceptance_rate": round(tr.acceptance_rate, 4),
+            "parity_vs_gpu": {"first_mismatch": first,
+                              "oracle_margin_there": None if first is None else round(tr.margins[first], 4),
+                              "tokens_compared": min(len(got.predicted_tokens), len(tr.predicted_tokens))}}
+
+
+if __name__ == "__main__":
+    main()

@@ -180,6 +180,7 @@ struct lsk_engine {
     bf16_t* qbuf = nullptr;       // [16][n_heads*hd]
     bf16_t* attn = nullptr;       // [16][n_heads*hd]
     bf16_t* act = nullptr;        // [16][I]
+    float* attn_part = nullptr;   // [n_heads][n_pages][16][hd + 2] split-KV partials
     bf16_t* kv_pool = nullptr;
     size_t kv_layer_elems = 0;    // elements per layer (K and V)
     size_t kv_half_elems = 0;     // elements of K (or V) per layer
@@ -197,7 +198,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
     size_t state, zero, block_table, row_tokens, verified, eos, result, bulk_ids, part_val, part_idx, hrow, hbulk, qbuf,
-        attn, act, total;
+        attn, act, attn_part, total;
     int max_parts, n_pages;
 };
 
@@ -208,7 +209,7 @@ static int check_cfg(const lsk_config* c) {
     if ((c->n_heads * c->head_dim) % 32) return lsk_fail("n_heads*head_dim must be a multiple of 32");
     if (c->intermediate % 16) return lsk_fail("intermediate must be a multiple of 16");
     if (c->n_heads % c->n_kv_heads) return lsk_fail("n_heads must be a multiple of n_kv_heads");
-    if (c->page_size <= 0 || c->page_size % 32) return lsk_fail("page_size must be a positive multiple of 32");
+    if (c->page_size != LSK_ATTN_PAGE) return lsk_fail("page_size must be %d", LSK_ATTN_PAGE);
     if (c->max_ctx <= 0 || c->max_ctx % c->page_size) return lsk_fail("max_ctx must be a positive multiple of page_size");
     if (c->num_layers <= 0 || c->vocab <= 0 || c->max_prompt < 0) return lsk_fail("bad geometry");
     return 0;
@@ -236,6 +237,7 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.qbuf = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
     L.attn = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
     L.act = take(2 * (size_t)LSK_MAX_ROWS * c->intermediate);
+    L.attn_part = take(sizeof(float) * (size_t)c->n_heads * L.n_pages * LSK_MAX_ROWS * (c->head_dim + 2));
     L.total = off;
     return L;
 }
@@ -328,6 +330,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->qbuf = (bf16_t*)(e->ws + L.qbuf);
     e->attn = (bf16_t*)(e->ws + L.attn);
     e->act = (bf16_t*)(e->ws + L.act);
+    e->attn_part = (float*)(e->ws + L.attn_part);
     e->kv_pool = (bf16_t*)kv_pool;
     e->kv_half_elems = (size_t)cfg->max_ctx * cfg->n_kv_heads * cfg->head_dim;
     e->kv_layer_elems = 2 * e->kv_half_elems;
@@ -445,19 +448,33 @@ static int check_rows(lsk_engine* e, int buffer, int row_base, int m) {
     return 0;
 }
 
-static int launch_attn(lsk_engine* e, AttnParams& ap, hipStream_t st) {
-    const int hd = e->cfg.head_dim;
-    const int M = ap.M;
-    const int rm = (M == 1) ? 1 : (M <= 4 ? 4 : 8);
-    const size_t lds = (size_t)LSK_WAVES * rm * (hd + 2) * sizeof(float);
-    const dim3 grid(e->cfg.n_heads), block(LSK_THREADS);
-#define LSK_ATTN_CASE(HD, RM) hipLaunchKernelGGL((lsk_attn_kernel<HD, RM>), grid, block, lds, st, ap)
+static int launch_attn(lsk_engine* e, const bf16_t* kpool, const bf16_t* vpool, int m, int pos_off, hipStream_t st) {
+    const lsk_config& c = e->cfg;
+    const int hd = c.head_dim;
+    const int qdim = c.n_heads * hd;
+    AttnSplitParams sp{};
+    sp.q = e->qbuf; sp.ldq = qdim; sp.kpool = kpool; sp.vpool = vpool; sp.block_table = e->block_table;
+    sp.n_kv = c.n_kv_heads; sp.group = c.n_heads / c.n_kv_heads; sp.M = m; sp.kv_len = &e->state->kv_len; sp.pos_off = pos_off;
+    sp.scale_log2e = (float)((1.0 / sqrt((double)hd)) * 1.4426950408889634);
+    sp.part = e->attn_part; sp.max_pages = e->n_pages;
+    const int last_pos = e->kv_len_host + pos_off + m - 1;
+    const int pages = last_pos / LSK_ATTN_PAGE + 1;
+    if (pages > e->n_pages) return lsk_fail("attention reaches page %d of %d", pages, e->n_pages);
+    const int rm = (m == 1) ? 1 : (m <= 4 ? 4 : 8);
+    const dim3 grid(c.n_heads, pages), block(LSK_ATTN_THREADS);
+#define LSK_ATTN_CASE(HD, RM) hipLaunchKernelGGL((lsk_attn_split_kernel<HD, RM>), grid, block, 0, st, sp)
     if (hd == 128) {
         if (rm == 1) LSK_ATTN_CASE(128, 1); else if (rm == 4) LSK_ATTN_CASE(128, 4); else LSK_ATTN_CASE(128, 8);
     } else {
         if (rm == 1) LSK_ATTN_CASE(64, 1); else if (rm == 4) LSK_ATTN_CASE(64, 4); else LSK_ATTN_CASE(64, 8);
     }
 #undef LSK_ATTN_CASE
+    HIP_OK(hipGetLastError());
+    AttnCombineParams cp{};
+    cp.part = e->attn_part; cp.max_pages = e->n_pages; cp.M = m; cp.kv_len = &e->state->kv_len; cp.pos_off = pos_off;
+    cp.out = e->attn; cp.ldo = qdim;
+    if (hd == 128) hipLaunchKernelGGL((lsk_attn_combine_kernel<128>), dim3(c.n_heads, m), dim3(128), 0, st, cp);
+    else hipLaunchKernelGGL((lsk_attn_combine_kernel<64>), dim3(c.n_heads, m), dim3(64), 0, st, cp);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -492,14 +509,7 @@ static int run_layers(lsk_engine* e, bf16_t* x, int m, const int* base_ptr, int 
             p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin; p.kv_len = base_ptr; p.pos_off = pos_off;
             LSK_TRY((launch_gemm<PRO_RMS, EPI_QKV>(p, e->target_wgs, st)));
         }
-        {
-            AttnParams ap{};
-            ap.q = e->qbuf; ap.ldq = qdim; ap.out = e->attn; ap.ldo = qdim; ap.kpool = kpool; ap.vpool = vpool;
-            ap.block_table = e->block_table; ap.page_size = c.page_size; ap.n_kv = c.n_kv_heads;
-            ap.group = c.n_heads / c.n_kv_heads; ap.M = m; ap.kv_len = base_ptr; ap.pos_off = pos_off;
-            ap.scale_log2e = (float)((1.0 / sqrt((double)c.head_dim)) * 1.4426950408889634);
-            LSK_TRY(launch_attn(e, ap, st));
-        }
+        LSK_TRY(launch_attn(e, kpool, vpool, m, pos_off, st));
         {   // o_proj + residual
             GemmParams p{};
             p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;

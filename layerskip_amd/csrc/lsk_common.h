@@ -73,24 +73,6 @@ struct GemmParams {
     int* part_idx;          // [grid][16]
 };
 
-// ---- decode attention ---------------------------------------------------------------------------
-struct AttnParams {
-    const bf16_t* q;        // [M][ldq]
-    int ldq;
-    bf16_t* out;            // [M][ldo]
-    int ldo;
-    const bf16_t* kpool;
-    const bf16_t* vpool;
-    const int* block_table;
-    int page_size;
-    int n_kv;
-    int group;              // n_heads / n_kv
-    int M;
-    const int* kv_len;
-    int pos_off;
-    float scale_log2e;      // head_dim^-0.5 * log2(e)
-};
-
 struct StepState {
     int kv_len;             // verified context length (all layers)
     int next_token;
