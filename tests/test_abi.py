@@ -1,0 +1,68 @@
+"""The C-ABI library loads on a GPU-less box and exports exactly what include/layerskip_hip.h declares."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "layerskip_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lsk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from layerskip_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    declared = _header_symbols()
+    assert declared, "no symbols parsed from the header"
+    assert sorted(_lib.PROTOTYPES) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.lsk_abi_version() == _lib.LSK_ABI_VERSION
+
+
+def test_size_queries_need_no_gpu():
+    from layerskip_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.LskConfig(32, 4096, 11008, 32, 32, 128, 32000, 1e-5, 1152, 128, 512, 0)
+    ws, kv, pk = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _lib.check(lib.lsk_workspace_bytes(ctypes.byref(cfg), ctypes.byref(ws)))
+    _lib.check(lib.lsk_kv_pool_bytes(ctypes.byref(cfg), ctypes.byref(kv)))
+    _lib.check(lib.lsk_packed_bytes(11008, 4096, ctypes.byref(pk)))
+    assert kv.value == 32 * 2 * 1152 * 32 * 128 * 2
+    assert pk.value == 11008 * 4096 * 2
+    assert ws.value > 16 * 4096 * 2
+    # ragged N pads to a whole 16-row tile
+    _lib.check(lib.lsk_packed_bytes(1000, 512, ctypes.byref(pk)))
+    assert pk.value == 1008 * 512 * 2
+
+
+def test_errors_are_status_codes_with_messages():
+    from layerskip_amd import _lib
+    lib = _lib.load()
+    bad = _lib.LskConfig(32, 4096, 11008, 32, 32, 96, 32000, 1e-5, 1152, 128, 512, 0)   # head_dim 96
+    out = ctypes.c_size_t(0)
+    assert lib.lsk_workspace_bytes(ctypes.byref(bad), ctypes.byref(out)) != 0
+    assert b"head_dim" in lib.lsk_last_error()
+    assert lib.lsk_packed_bytes(16, 100, ctypes.byref(out)) != 0          # k not a multiple of 32
+    try:
+        _lib.check(lib.lsk_packed_bytes(16, 100, ctypes.byref(out)))
+    except _lib.LskError as exc:
+        assert "multiple of 32" in str(exc)
+    else:
+        raise AssertionError("expected LskError")
+
+
+def test_engine_refuses_cpu_models():
+    """No silent CPU fallback: a model that is not on a HIP device is an error, not a slow path."""
+    import pytest
+    import torch
+    from layerskip_amd import _lib, synthetic
+    from layerskip_amd.engine import HipEngine
+    model = synthetic.build_model(synthetic.make_config("tiny-mha"), seed=0, exit_layer=2)
+    with pytest.raises(_lib.LskError):
+        HipEngine(model)
+    assert not torch.cuda.is_available() or True
