@@ -150,6 +150,14 @@ int lsk_embed_rows(lsk_engine* e, const int32_t* ids, int32_t n, int32_t buffer,
  * llama_model_utils.py:193,253,354,375).  m <= LSK_MAX_ROWS. */
 int lsk_run_layers(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, int32_t pos_offset,
                    int32_t layer_begin, int32_t layer_end, void* stream);
+/* Rows [0, n) of the bulk buffer through layers [layer_begin, layer_end), row i at position
+ * kv_len + i: the prompt-prefill part of forward / forward_early / forward_remainder
+ * (llama_model_utils.py:192-201, :252-261, :375-383 with M = prompt length).  Uses the MFMA-tiled
+ * prefill kernels from LSK_OPT_BIG_THRESHOLD rows on, 16-row passes of the decode kernels below. */
+int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_end, void* stream);
+#define LSK_OPT_BIG_THRESHOLD 1   /* rows from which prefill uses the MFMA-tiled kernels (default 48) */
+#define LSK_OPT_TARGET_WGS 2      /* workgroups per skinny projection launch (default 256) */
+int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
 /* Final RMSNorm + lm_head (+ greedy argmax) over rows [row_base, row_base+m)
  * (llama_model_utils.py:204-205, :271-273, :386-387; decode_next_token :120-122).
  * logits_out: optional device fp32 [m][ld_logits] (values are bf16-rounded like the model dtype);

@@ -13,6 +13,8 @@ LSK_MAX_ROWS = 16
 LSK_MAX_SPEC = 15
 LSK_MAX_EOS = 8
 LSK_ABI_VERSION = 1
+LSK_OPT_BIG_THRESHOLD = 1
+LSK_OPT_TARGET_WGS = 2
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblayerskip_hip.so")
 
@@ -56,6 +58,8 @@ PROTOTYPES = {
     "lsk_ar_step": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, POINTER(c_int32), c_void_p]),
     "lsk_embed_rows": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
     "lsk_run_layers": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_run_bulk": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_engine_set_option": (c_int32, [c_void_p, c_int32, c_int32]),
     "lsk_run_head": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
     "lsk_read_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "lsk_write_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

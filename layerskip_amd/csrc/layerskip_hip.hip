@@ -16,6 +16,7 @@
 #include "lsk_attn.h"
 #include "lsk_common.h"
 #include "lsk_gemm.h"
+#include "lsk_gemm_big.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -181,6 +182,7 @@ struct lsk_engine {
     bf16_t* attn = nullptr;       // [16][n_heads*hd]
     bf16_t* act = nullptr;        // [16][I]
     float* attn_part = nullptr;   // [n_heads][n_pages][16][hd + 2] split-KV partials
+    bf16_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]
     bf16_t* kv_pool = nullptr;
     size_t kv_layer_elems = 0;    // elements per layer (K and V)
     size_t kv_half_elems = 0;     // elements of K (or V) per layer
@@ -188,6 +190,7 @@ struct lsk_engine {
     int n_pages = 0;
     int kv_len_host = 0;          // mirror of state->kv_len
     int target_wgs = 256;
+    int big_threshold = 48;       // prompt rows from which the MFMA-tiled prefill kernels take over
     // profiling of the dominant kernel (gate/up projection)
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
@@ -198,7 +201,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
     size_t state, zero, block_table, row_tokens, verified, eos, result, bulk_ids, part_val, part_idx, hrow, hbulk, qbuf,
-        attn, act, attn_part, total;
+        attn, act, attn_part, xn_bulk, q_bulk, attn_bulk, act_bulk, total;
     int max_parts, n_pages;
 };
 
@@ -238,6 +241,10 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.attn = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
     L.act = take(2 * (size_t)LSK_MAX_ROWS * c->intermediate);
     L.attn_part = take(sizeof(float) * (size_t)c->n_heads * L.n_pages * LSK_MAX_ROWS * (c->head_dim + 2));
+    L.xn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->hidden);
+    L.q_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
+    L.attn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
+    L.act_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->intermediate);
     L.total = off;
     return L;
 }
@@ -331,6 +338,10 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->attn = (bf16_t*)(e->ws + L.attn);
     e->act = (bf16_t*)(e->ws + L.act);
     e->attn_part = (float*)(e->ws + L.attn_part);
+    e->xn_bulk = (bf16_t*)(e->ws + L.xn_bulk);
+    e->q_bulk = (bf16_t*)(e->ws + L.q_bulk);
+    e->attn_bulk = (bf16_t*)(e->ws + L.attn_bulk);
+    e->act_bulk = (bf16_t*)(e->ws + L.act_bulk);
     e->kv_pool = (bf16_t*)kv_pool;
     e->kv_half_elems = (size_t)cfg->max_ctx * cfg->n_kv_heads * cfg->head_dim;
     e->kv_layer_elems = 2 * e->kv_half_elems;
@@ -448,31 +459,25 @@ static int check_rows(lsk_engine* e, int buffer, int row_base, int m) {
     return 0;
 }
 
-static int launch_attn(lsk_engine* e, const bf16_t* kpool, const bf16_t* vpool, int m, int pos_off, hipStream_t st) {
+static int launch_attn(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t* kpool, const bf16_t* vpool, int m, int pos_off, hipStream_t st) {
     const lsk_config& c = e->cfg;
     const int hd = c.head_dim;
     const int qdim = c.n_heads * hd;
     AttnSplitParams sp{};
-    sp.q = e->qbuf; sp.ldq = qdim; sp.kpool = kpool; sp.vpool = vpool; sp.block_table = e->block_table;
+    sp.q = q; sp.ldq = qdim; sp.kpool = kpool; sp.vpool = vpool; sp.block_table = e->block_table;
     sp.n_kv = c.n_kv_heads; sp.group = c.n_heads / c.n_kv_heads; sp.M = m; sp.kv_len = &e->state->kv_len; sp.pos_off = pos_off;
     sp.scale_log2e = (float)((1.0 / sqrt((double)hd)) * 1.4426950408889634);
     sp.part = e->attn_part; sp.max_pages = e->n_pages;
     const int last_pos = e->kv_len_host + pos_off + m - 1;
     const int pages = last_pos / LSK_ATTN_PAGE + 1;
     if (pages > e->n_pages) return lsk_fail("attention reaches page %d of %d", pages, e->n_pages);
-    const int rm = (m == 1) ? 1 : (m <= 4 ? 4 : 8);
     const dim3 grid(c.n_heads, pages), block(LSK_ATTN_THREADS);
-#define LSK_ATTN_CASE(HD, RM) hipLaunchKernelGGL((lsk_attn_split_kernel<HD, RM>), grid, block, 0, st, sp)
-    if (hd == 128) {
-        if (rm == 1) LSK_ATTN_CASE(128, 1); else if (rm == 4) LSK_ATTN_CASE(128, 4); else LSK_ATTN_CASE(128, 8);
-    } else {
-        if (rm == 1) LSK_ATTN_CASE(64, 1); else if (rm == 4) LSK_ATTN_CASE(64, 4); else LSK_ATTN_CASE(64, 8);
-    }
-#undef LSK_ATTN_CASE
+    if (hd == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, sp);
+    else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, sp);
     HIP_OK(hipGetLastError());
     AttnCombineParams cp{};
     cp.part = e->attn_part; cp.max_pages = e->n_pages; cp.M = m; cp.kv_len = &e->state->kv_len; cp.pos_off = pos_off;
-    cp.out = e->attn; cp.ldo = qdim;
+    cp.out = out; cp.ldo = qdim;
     if (hd == 128) hipLaunchKernelGGL((lsk_attn_combine_kernel<128>), dim3(c.n_heads, m), dim3(128), 0, st, cp);
     else hipLaunchKernelGGL((lsk_attn_combine_kernel<64>), dim3(c.n_heads, m), dim3(64), 0, st, cp);
     HIP_OK(hipGetLastError());
@@ -509,7 +514,7 @@ static int run_layers(lsk_engine* e, bf16_t* x, int m, const int* base_ptr, int 
             p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin; p.kv_len = base_ptr; p.pos_off = pos_off;
             LSK_TRY((launch_gemm<PRO_RMS, EPI_QKV>(p, e->target_wgs, st)));
         }
-        LSK_TRY(launch_attn(e, kpool, vpool, m, pos_off, st));
+        LSK_TRY(launch_attn(e, e->qbuf, e->attn, kpool, vpool, m, pos_off, st));
         {   // o_proj + residual
             GemmParams p{};
             p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
@@ -559,9 +564,68 @@ static int embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, bf16_t* d
     return 0;
 }
 
-// rows [0, n) of the bulk buffer (already embedded or holding exit hiddens) through layers [lb, le),
-// 16 rows per pass, row r at position *base_ptr + r.
+template <int EPI>
+static int launch_big(BigGemmParams& p, hipStream_t st) {
+    const dim3 grid((p.M + LSK_BIG_BM - 1) / LSK_BIG_BM, (p.n_tiles + 7) / 8);
+    hipLaunchKernelGGL((lsk_gemm_big_kernel<EPI>), grid, dim3(LSK_BIG_THREADS), 0, st, p);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// Prompt rows [0, n) of the bulk buffer through layers [lb, le) with the MFMA-tiled prefill kernels.
+static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
+    const lsk_config& c = e->cfg;
+    const int qdim = c.n_heads * c.head_dim;
+    const int kvdim = c.n_kv_heads * c.head_dim;
+    const int* kvp = &e->state->kv_len;
+    for (int l = lb; l < le; ++l) {
+        const LayerWeights& lw = e->layers[l];
+        bf16_t* kpool = e->kv_pool + (size_t)l * e->kv_layer_elems;
+        bf16_t* vpool = kpool + e->kv_half_elems;
+        hipLaunchKernelGGL(lsk_rmsnorm_rows_kernel, dim3(n), dim3(256), 0, st, e->hbulk, c.hidden, lw.norm1, c.rms_eps, c.hidden, e->xn_bulk, c.hidden);
+        HIP_OK(hipGetLastError());
+        {
+            BigGemmParams p{};
+            p.x = e->xn_bulk; p.ldx = c.hidden; p.M = n; p.K = c.hidden; p.wp = lw.wqkv; p.N = qdim + 2 * kvdim; p.n_tiles = p.N / 16;
+            p.q_out = e->q_bulk; p.ldq = qdim; p.kpool = kpool; p.vpool = vpool; p.block_table = e->block_table; p.page_size = c.page_size;
+            p.n_heads = c.n_heads; p.n_kv = c.n_kv_heads; p.head_dim = c.head_dim; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
+            p.kv_len = kvp; p.pos_off = 0;
+            LSK_TRY(launch_big<EPI_QKV>(p, st));
+        }
+        for (int r0 = 0; r0 < n; r0 += LSK_MAX_ROWS) {
+            const int m = (n - r0) < LSK_MAX_ROWS ? (n - r0) : LSK_MAX_ROWS;
+            LSK_TRY(launch_attn(e, e->q_bulk + (size_t)r0 * qdim, e->attn_bulk + (size_t)r0 * qdim, kpool, vpool, m, r0, st));
+        }
+        {
+            BigGemmParams p{};
+            p.x = e->attn_bulk; p.ldx = qdim; p.M = n; p.K = qdim; p.wp = lw.wo; p.N = c.hidden; p.n_tiles = p.N / 16;
+            p.h = e->hbulk; p.ldh = c.hidden;
+            LSK_TRY(launch_big<EPI_RESID>(p, st));
+        }
+        hipLaunchKernelGGL(lsk_rmsnorm_rows_kernel, dim3(n), dim3(256), 0, st, e->hbulk, c.hidden, lw.norm2, c.rms_eps, c.hidden, e->xn_bulk, c.hidden);
+        HIP_OK(hipGetLastError());
+        {
+            BigGemmParams p{};
+            p.x = e->xn_bulk; p.ldx = c.hidden; p.M = n; p.K = c.hidden; p.wp = lw.wgu; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
+            p.act = e->act_bulk; p.ldact = c.intermediate;
+            LSK_TRY(launch_big<EPI_SWIGLU>(p, st));
+        }
+        {
+            BigGemmParams p{};
+            p.x = e->act_bulk; p.ldx = c.intermediate; p.M = n; p.K = c.intermediate; p.wp = lw.wdown; p.N = c.hidden; p.n_tiles = p.N / 16;
+            p.h = e->hbulk; p.ldh = c.hidden;
+            LSK_TRY(launch_big<EPI_RESID>(p, st));
+        }
+    }
+    return 0;
+}
+
+// rows [0, n) of the bulk buffer (already embedded or holding exit hiddens) through layers [lb, le):
+// MFMA-tiled prefill kernels for real prompts, 16-row passes of the decode kernels for short ones.
 static int run_bulk(lsk_engine* e, int n, const int* base_ptr, int lb, int le, hipStream_t st) {
+    const lsk_config& c = e->cfg;
+    const bool big_ok = (c.hidden % LSK_BIG_BK == 0) && ((c.n_heads * c.head_dim) % LSK_BIG_BK == 0) && (c.intermediate % LSK_BIG_BK == 0);
+    if (n >= e->big_threshold && big_ok) return run_bulk_big(e, n, lb, le, st);
     for (int r0 = 0; r0 < n; r0 += LSK_MAX_ROWS) {
         const int m = (n - r0) < LSK_MAX_ROWS ? (n - r0) : LSK_MAX_ROWS;
         LSK_TRY(run_layers(e, e->hbulk + (size_t)r0 * e->cfg.hidden, m, base_ptr, r0, lb, le, st));
@@ -681,6 +745,23 @@ extern "C" int lsk_run_layers(lsk_engine* e, int32_t buffer, int32_t row_base, i
     if (layer_begin < 0 || layer_end > e->cfg.num_layers || layer_begin > layer_end) return lsk_fail("bad layer range [%d,%d)", layer_begin, layer_end);
     if (pos_offset < 0 || e->kv_len_host + pos_offset + m > e->cfg.max_ctx) return lsk_fail("positions exceed max_ctx");
     return run_layers(e, buf_rows(e, buffer, row_base), m, &e->state->kv_len, pos_offset, layer_begin, layer_end, (hipStream_t)stream);
+}
+
+extern "C" int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_end, void* stream) {
+    LSK_TRY(ready(e));
+    if (n < 1 || n > e->cfg.max_prompt + 16) return lsk_fail("lsk_run_bulk: %d rows out of range", n);
+    if (layer_begin < 0 || layer_end > e->cfg.num_layers || layer_begin > layer_end) return lsk_fail("bad layer range [%d,%d)", layer_begin, layer_end);
+    if (e->kv_len_host + n > e->cfg.max_ctx) return lsk_fail("positions exceed max_ctx");
+    return run_bulk(e, n, &e->state->kv_len, layer_begin, layer_end, (hipStream_t)stream);
+}
+
+extern "C" int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value) {
+    if (!e) return lsk_fail("null engine");
+    switch (option) {
+        case LSK_OPT_BIG_THRESHOLD: e->big_threshold = value; return 0;
+        case LSK_OPT_TARGET_WGS: e->target_wgs = value > 0 ? value : 256; return 0;
+        default: return lsk_fail("unknown option %d", option);
+    }
 }
 
 extern "C" int lsk_run_head(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, void* logits_out, int32_t ld_logits,

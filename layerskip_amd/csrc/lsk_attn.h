@@ -1,20 +1,24 @@
-// Decode / verify attention over the paged KV pool, split over KV pages ("flash-decoding" shape).
+// Decode / verify attention over the paged KV pool, split over KV pages ("flash-decoding" shape),
+// QK^T and PV on bf16 MFMA.
 //
 //   grid  = (n_heads, pages in reach)      block = 4 waves
-//   phase 1 (lsk_attn_split_kernel): one workgroup = one query head x ONE 128-token KV page.  Each
-//           wave owns 32 consecutive keys and issues ALL of its K and V loads up front (16 x 1 KiB
-//           per wave in flight, the page layout [kv_head][slot][head_dim] makes every wave-load one
-//           contiguous 1 KiB segment), so ~256 workgroups keep >8 MiB of KV reads in flight -- the
-//           kernel is HBM/L2-latency bound, not math bound.  The M <= 16 query rows are walked in
-//           register passes of RM rows over the SAME K/V registers (no re-read), fp32 online softmax
-//           per lane-group stream, streams merged in a fixed tree, result = one (max, sum, acc[d])
-//           partial per (row, head, page).
-//   phase 2 (lsk_attn_combine_kernel): merges the page partials of a (row, head) in page order and
-//           writes the bf16 attention output.
-// Causality is index arithmetic: row r sits at position base + r and sees keys <= its position
-// (this replaces the additive float masks of llama_model_utils.py:21-59).  The partition of keys
-// into streams depends only on the absolute key index, so a row's result never depends on M or on
-// the other rows of the pass.
+//   phase 1 (lsk_attn_split_kernel): one workgroup = one query head x ONE 128-token KV page, one wave
+//           = 32 consecutive keys.  A wave issues ALL of its loads up front -- K as MFMA B-fragments
+//           straight from the page ([kv_head][slot][d] rows, 64 B per key per k-step), V as B-fragments
+//           from the TRANSPOSED page ([kv_head][d][slot]: 8 consecutive keys of one feature are 16
+//           contiguous bytes), Q as A-fragments (rows = the M <= 16 query rows) -- so ~256 workgroups
+//           keep > 4 MiB of KV reads in flight: the kernel is latency/bandwidth bound, the math
+//           (8 + 8 MFMAs per wave) is free.  S = QK^T lands in the MFMA C layout; causal masking is
+//           index arithmetic (row r at position base + r sees keys <= its position; this replaces the
+//           additive masks of llama_model_utils.py:21-59); fp32 softmax statistics per row via 16-lane
+//           butterflies; P is rounded to bf16 (as HF's eager path and torch's CPU flash kernel both do
+//           before the second GEMM), transposed C->A layout through 1 KiB of LDS per wave, O = P V.
+//           The 4 waves are merged in a fixed order into ONE (max, sum, acc[d]) partial per
+//           (row, head, page).
+//   phase 2 (lsk_attn_combine_kernel): merges the page partials of a (row, head) in page order, writes
+//           the bf16 attention output.
+// Every row of the MFMA tiles is computed independently and the key partition depends only on the
+// absolute key index, so a row's result never depends on M or on the other rows of the pass.
 // Replaces: LlamaAttention's repeat_kv + eager/SDPA attention (modeling_llama.py:179-213, :264-277).
 #pragma once
 #include "lsk_common.h"
@@ -23,12 +27,13 @@
 #define LSK_ATTN_THREADS 256
 #define LSK_ATTN_WAVES 4
 #define LSK_ATTN_PAGE 128          // keys per workgroup == KV page size
+#define LSK_ATTN_MAXP 64           // pages the combine kernel prefetches in one go
 
 struct AttnSplitParams {
     const bf16_t* q;        // [M][ldq]
     int ldq;
-    const bf16_t* kpool;    // this layer's K pages [page][n_kv][page_size][head_dim]
-    const bf16_t* vpool;
+    const bf16_t* kpool;    // this layer's K pages  [page][n_kv][page_size][head_dim]
+    const bf16_t* vpool;    // this layer's V^T pages [page][n_kv][head_dim][page_size]
     const int* block_table;
     int n_kv;
     int group;              // n_heads / n_kv
@@ -50,13 +55,14 @@ struct AttnCombineParams {
     int ldo;
 };
 
-template <int HD, int RM>
+template <int HD>
 __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const AttnSplitParams p) {
-    constexpr int LPK = HD / 8;              // lanes per key
-    constexpr int KPW = 64 / LPK;            // keys per wave-load
-    constexpr int NL = 32 / KPW;             // wave-loads per wave (32 keys per wave)
+    constexpr int KS = HD / 32;              // k-steps of QK^T
+    constexpr int DT = HD / 16;              // output column tiles of PV
     constexpr int PSTRIDE = HD + 2;
-    __shared__ float sm[LSK_ATTN_WAVES * RM * PSTRIDE];
+    constexpr int PB_STRIDE = 80;            // bytes per P row in LDS: 32 bf16 + 16 B pad
+    __shared__ __attribute__((aligned(16))) unsigned char pbuf[LSK_ATTN_WAVES * 16 * PB_STRIDE];
+    __shared__ float sm[LSK_ATTN_WAVES * 16 * PSTRIDE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,111 +70,100 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const 
     const int head = blockIdx.x;
     const int page_l = blockIdx.y;           // logical page
     const int kvh = head / p.group;
-    const int ksub = lane / LPK;
-    const int dch = lane % LPK;
+    const int c16 = lane & 15;
+    const int g = lane >> 4;
     const int base_pos = *p.kv_len + p.pos_off;
     const int M = p.M;
     const int key0 = page_l * LSK_ATTN_PAGE;
     if (key0 > base_pos + M - 1) return;     // page entirely in the future of every row
 
-    // ---- all K / V loads of this wave up front ----
+    // ---- every load of this wave up front ----
     const int page = p.block_table[page_l];
-    const size_t pbase = (((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE + w * 32) * HD + (size_t)lane * 8;
-    bf16x8 kreg[NL], vreg[NL];
+    const size_t head_base = ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD;
+    const bf16_t* kp = p.kpool + head_base + (size_t)(w * 32 + c16) * HD + g * 8;
+    const bf16_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + w * 32 + g * 8;
+    const bf16_t* qp = p.q + (size_t)min(c16, M - 1) * p.ldq + head * HD + g * 8;
+    bf16x8 kb[2][KS], vb[DT], qa[KS];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        kreg[i] = *(const bf16x8*)(p.kpool + pbase + (size_t)i * KPW * HD);
-        vreg[i] = *(const bf16x8*)(p.vpool + pbase + (size_t)i * KPW * HD);
+    for (int ks = 0; ks < KS; ++ks) {
+        kb[0][ks] = *(const bf16x8*)(kp + ks * 32);
+        kb[1][ks] = *(const bf16x8*)(kp + 16 * HD + ks * 32);
+        qa[ks] = *(const bf16x8*)(qp + ks * 32);
     }
-    const int wkey0 = key0 + w * 32;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const bf16x8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
 
-    for (int r0 = 0; r0 < M; r0 += RM) {
-        const int rows = min(RM, M - r0);
-        float qf[RM][8], acc[RM][8], mrun[RM], lrun[RM];
+    // ---- S = Q K^T (C layout: column = key, rows g*4 + r) ----
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const int row = r0 + min(r, rows - 1);
-            const bf16x8 qv = *(const bf16x8*)(p.q + (size_t)row * p.ldq + head * HD + dch * 8);
+    for (int ks = 0; ks < KS; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[0][ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[1][ks], s1, 0, 0, 0);
+    }
+    const int keyA = key0 + w * 32 + c16;    // key of s0's column; s1's is keyA + 16
+    float mrow[4], lrow[4];
+    unsigned char* pw = pbuf + w * 16 * PB_STRIDE;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { qf[r][j] = bf2f(qv[j]) * p.scale_log2e; acc[r][j] = 0.f; }
-            mrun[r] = LSK_ATTN_NEG;
-            lrun[r] = 0.f;
+    for (int r = 0; r < 4; ++r) {
+        const int row = g * 4 + r;
+        const int lim = base_pos + row;      // last visible key of this row
+        const bool ok0 = (row < M) && (keyA <= lim);
+        const bool ok1 = (row < M) && (keyA + 16 <= lim);
+        const float a0 = ok0 ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
+        const float a1 = ok1 ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
+        float m = fmaxf(a0, a1);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const float p0 = ok0 ? __builtin_amdgcn_exp2f(a0 - m) : 0.f;
+        const float p1 = ok1 ? __builtin_amdgcn_exp2f(a1 - m) : 0.f;
+        float l = p0 + p1;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+        mrow[r] = m;
+        lrow[r] = l;
+        *(bf16_t*)(pw + row * PB_STRIDE + c16 * 2) = f2bf(p0);
+        *(bf16_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2bf(p1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- O = P V : A fragment = P[row c16][keys g*8 .. g*8+7] ----
+    const bf16x8 pa = *(const bf16x8*)(pw + c16 * PB_STRIDE + g * 16);
+    float* dst = sm + (size_t)w * 16 * PSTRIDE;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb[dt], o, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(g * 4 + r) * PSTRIDE + dt * 16 + c16] = o[r];
+    }
+    if (c16 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dst[(g * 4 + r) * PSTRIDE + HD] = mrow[r];
+            dst[(g * 4 + r) * PSTRIDE + HD + 1] = lrow[r];
         }
+    }
+    __syncthreads();
+    // ---- merge the 4 waves (fixed order) into the page partial ----
+    for (int e = tid; e < M * PSTRIDE; e += LSK_ATTN_THREADS) {
+        const int r = e / PSTRIDE;
+        const int d = e - r * PSTRIDE;
+        float m = LSK_ATTN_NEG;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int key = wkey0 + i * KPW + ksub;
-            float kf[8], vf[8];
+        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + r) * PSTRIDE + HD]);
+        float v;
+        if (d == HD) {
+            v = m;
+        } else {
+            v = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { kf[j] = bf2f(kreg[i][j]); vf[j] = bf2f(vreg[i][j]); }
-#pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s = fmaf(qf[r][j], kf[j], s);
-#pragma unroll
-                for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                const bool valid = (r < rows) && (key <= base_pos + r0 + r);
-                if (valid) {
-                    if (s > mrun[r]) {
-                        const float alpha = __builtin_amdgcn_exp2f(mrun[r] - s);
-                        lrun[r] *= alpha;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[r][j] *= alpha;
-                        mrun[r] = s;
-                    }
-                    const float pr = __builtin_amdgcn_exp2f(s - mrun[r]);
-                    lrun[r] += pr;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[r][j] = fmaf(pr, vf[j], acc[r][j]);
-                }
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
+                const float* src = sm + (ww * 16 + r) * PSTRIDE;
+                v += src[d] * __builtin_amdgcn_exp2f(src[HD] - m);      // d == HD + 1: the running sum l
             }
         }
-        // merge the lane-group streams of the wave (fixed tree), then the 4 waves through LDS
-#pragma unroll
-        for (int r = 0; r < RM; ++r) {
-#pragma unroll
-            for (int o = LPK; o < 64; o <<= 1) {
-                const float mo = __shfl_xor(mrun[r], o, 64);
-                const float lo = __shfl_xor(lrun[r], o, 64);
-                const float mn = fmaxf(mrun[r], mo);
-                const float a = __builtin_amdgcn_exp2f(mrun[r] - mn);
-                const float b = __builtin_amdgcn_exp2f(mo - mn);
-                lrun[r] = lrun[r] * a + lo * b;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float ao = __shfl_xor(acc[r][j], o, 64);
-                    acc[r][j] = acc[r][j] * a + ao * b;
-                }
-                mrun[r] = mn;
-            }
-            if (ksub == 0) {
-                float* dst = sm + (w * RM + r) * PSTRIDE;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dst[dch * 8 + j] = acc[r][j];
-                if (dch == 0) { dst[HD] = mrun[r]; dst[HD + 1] = lrun[r]; }
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < rows * PSTRIDE; e += LSK_ATTN_THREADS) {
-            const int r = e / PSTRIDE;
-            const int d = e - r * PSTRIDE;
-            float m = LSK_ATTN_NEG;
-#pragma unroll
-            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * RM + r) * PSTRIDE + HD]);
-            float v;
-            if (d == HD) {
-                v = m;
-            } else {
-                v = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
-                    const float* src = sm + (ww * RM + r) * PSTRIDE;
-                    v += src[d] * __builtin_amdgcn_exp2f(src[HD] - m);      // d == HD+1: the running sum l
-                }
-            }
-            p.part[(((size_t)head * p.max_pages + page_l) * LSK_ROWS + (r0 + r)) * PSTRIDE + d] = v;
-        }
-        __syncthreads();
+        p.part[(((size_t)head * p.max_pages + page_l) * LSK_ROWS + r) * PSTRIDE + d] = v;
     }
 }
 
@@ -182,15 +177,25 @@ __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineP
     const int n_pages = pos / LSK_ATTN_PAGE + 1;
     const float* base = p.part + (((size_t)head * p.max_pages) * LSK_ROWS + row) * PSTRIDE;
     float m = LSK_ATTN_NEG, l = 0.f, a = 0.f;
-    for (int pg = 0; pg < n_pages; ++pg) {
-        const float* src = base + (size_t)pg * LSK_ROWS * PSTRIDE;
-        const float mo = src[HD], lo = src[HD + 1], ao = src[d];
-        const float mn = fmaxf(m, mo);
-        const float fa = __builtin_amdgcn_exp2f(m - mn);
-        const float fb = __builtin_amdgcn_exp2f(mo - mn);
-        l = l * fa + lo * fb;
-        a = a * fa + ao * fb;
-        m = mn;
+    for (int p0 = 0; p0 < n_pages; p0 += 8) {
+        float mo[8], lo[8], ao[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {           // independent loads first: one L2 round trip per 8 pages
+            const int pg = min(p0 + i, n_pages - 1);
+            const float* src = base + (size_t)pg * LSK_ROWS * PSTRIDE;
+            mo[i] = src[HD]; lo[i] = src[HD + 1]; ao[i] = src[d];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (p0 + i < n_pages) {
+                const float mn = fmaxf(m, mo[i]);
+                const float fa = __builtin_amdgcn_exp2f(m - mn);
+                const float fb = __builtin_amdgcn_exp2f(mo[i] - mn);
+                l = l * fa + lo[i] * fb;
+                a = a * fa + ao[i] * fb;
+                m = mn;
+            }
+        }
     }
     p.out[(size_t)row * p.ldo + head * HD + d] = f2bf(a / l);
 }

@@ -247,8 +247,9 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
                     } else {
                         const int page = p.block_table[pos / p.page_size];
                         const int slot = pos % p.page_size;
-                        bf16_t* pool = (kind == 1) ? p.kpool : p.vpool;
-                        pool[(((size_t)page * p.n_kv + head) * p.page_size + slot) * hd + feat] = f2bf(v);
+                        const size_t hb = ((size_t)page * p.n_kv + head) * p.page_size * hd;
+                        if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2bf(v);        // K page  [slot][d]
+                        else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2bf(v);         // V^T page [d][slot]
                     }
                 }
             }

@@ -1,0 +1,236 @@
+// Prompt-prefill projection kernel: Y[M ~ 512][N] = X[M][K] @ W[N][K]^T on bf16 MFMA, same packed
+// weight tiles as the skinny decode kernel (so no second copy of the weights exists).
+//
+// MFMA-bound (M >= 128 rows => >= 128 FLOP per weight byte), one-off per generation (<= 2 % of the
+// path's time), so this is the plain LDS-tiled shape: 128-row x 128-column output tile per 4-wave
+// workgroup, A tile (activations) staged through a double-buffered, padded LDS image, B fragments
+// (weights) straight from the packed tiles to VGPRs (each wave owns two adjacent 16-column tiles, i.e.
+// exactly one gate/up pair or one RoPE tile pair), register-prefetch of the next K-tile under the
+// current MFMAs, one barrier per K-tile.  blockIdx.x walks the row blocks so the workgroups that share
+// a weight panel are dispatched together (panel re-reads hit L2 / Infinity Cache, not HBM).
+// Epilogues are the ones of lsk_gemm.h (bf16 rounding points of the HF modules).
+// Only prompt rows that are NOT decision rows go through here (their logits are never used), so the
+// different accumulation order never reaches an argmax; it only fills KV pages / exit hiddens.
+#pragma once
+#include "lsk_common.h"
+
+#define LSK_BIG_BM 128
+#define LSK_BIG_BK 64
+#define LSK_BIG_THREADS 256
+#define LSK_BIG_LDA 144          // bytes per LDS row: 64 bf16 + 16 B pad
+
+struct BigGemmParams {
+    const bf16_t* x;        // [M][ldx]
+    int ldx;
+    int M;
+    int K;                  // multiple of 64
+    const bf16_t* wp;       // packed tiles
+    int N;
+    int n_tiles;
+    // EPI_RESID
+    bf16_t* h;
+    int ldh;
+    // EPI_SWIGLU
+    bf16_t* act;
+    int ldact;
+    // EPI_QKV
+    bf16_t* q_out;
+    int ldq;
+    bf16_t* kpool;
+    bf16_t* vpool;
+    const int* block_table;
+    int page_size;
+    int n_heads;
+    int n_kv;
+    int head_dim;
+    const bf16_t* rope_cos;
+    const bf16_t* rope_sin;
+    const int* kv_len;
+    int pos_off;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const BigGemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * LSK_BIG_BM * LSK_BIG_LDA];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * LSK_BIG_BM;
+    const int T0 = (blockIdx.y * 4 + w) * 2;             // this wave's first packed tile
+    const int ksteps = p.K >> 5;
+    const int nkt = p.K / LSK_BIG_BK;
+    const bool tile_ok = T0 < p.n_tiles;
+    const bool tile1_ok = T0 + 1 < p.n_tiles;
+
+    // A staging: thread -> (row, 64-byte half)
+    const int arow = tid >> 1;
+    const int ahalf = tid & 1;
+    const int grow = min(m0 + arow, p.M - 1);
+    const bf16_t* aptr = p.x + (size_t)grow * p.ldx + ahalf * 32;
+    unsigned char* awr = lds + arow * LSK_BIG_LDA + ahalf * 64;
+    // B fragments: packed tile T, k-step s at ((T*ksteps + s)*64 + lane)*8 elements
+    const bf16_t* bptr0 = p.wp + ((size_t)T0 * ksteps * 64 + lane) * 8;
+    const bf16_t* bptr1 = bptr0 + (size_t)ksteps * 512;
+
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 areg[4];
+    bf16x8 bcur[2][2], bnxt[2][2];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) areg[i] = *(const bf16x8*)(aptr + i * 8);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bcur[0][s] = tile_ok ? *(const bf16x8*)(bptr0 + (size_t)s * 512) : zero8;
+        bcur[1][s] = tile1_ok ? *(const bf16x8*)(bptr1 + (size_t)s * 512) : zero8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(bf16x8*)(awr + i * 16) = areg[i];
+    __syncthreads();
+
+    const unsigned char* ard = lds + (lane & 15) * LSK_BIG_LDA + (lane >> 4) * 16;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            const bf16_t* an = aptr + (size_t)(kt + 1) * LSK_BIG_BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) areg[i] = *(const bf16x8*)(an + i * 8);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const size_t bo = (size_t)((kt + 1) * 2 + s) * 512;
+                bnxt[0][s] = tile_ok ? *(const bf16x8*)(bptr0 + bo) : zero8;
+                bnxt[1][s] = tile1_ok ? *(const bf16x8*)(bptr1 + bo) : zero8;
+            }
+        }
+        const unsigned char* abase = ard + cur * (LSK_BIG_BM * LSK_BIG_LDA);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const bf16x8 a = *(const bf16x8*)(abase + mt * 16 * LSK_BIG_LDA + s * 64);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[0][s], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[1][s], acc[mt][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            unsigned char* dst = awr + (cur ^ 1) * (LSK_BIG_BM * LSK_BIG_LDA);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(bf16x8*)(dst + i * 16) = areg[i];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { bcur[0][s] = bnxt[0][s]; bcur[1][s] = bnxt[1][s]; }
+        }
+        __syncthreads();
+    }
+    if (!tile_ok) return;
+
+    const int c16 = lane & 15;
+    const int rg = lane >> 4;
+    if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = (T0 + nt) * 16 + c16;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + mt * 16 + rg * 4 + i;
+                    if (row < p.M && n < p.N) {
+                        bf16_t* hp = p.h + (size_t)row * p.ldh + n;
+                        *hp = f2bf(bf2f(*hp) + rbf(acc[mt][nt][i]));
+                    }
+                }
+        }
+    } else if (EPI == EPI_SWIGLU) {
+        const int n = (T0 >> 1) * 16 + c16;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + mt * 16 + rg * 4 + i;
+                if (row < p.M && n < (p.N >> 1)) {
+                    const float g = rbf(acc[mt][0][i]);
+                    const float uu = rbf(acc[mt][1][i]);
+                    const float s = rbf(g / (1.0f + expf(-g)));
+                    p.act[(size_t)row * p.ldact + n] = f2bf(s * uu);
+                }
+            }
+    } else if (EPI == EPI_QKV) {
+        const int hd = p.head_dim;
+        const int tph = hd >> 4;
+        const int nq_t = p.n_heads * tph;
+        const int nk_t = p.n_kv * tph;
+        const int base_pos = *p.kv_len + p.pos_off;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int T = T0 + nt;
+            if (T >= p.n_tiles) continue;
+            const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);
+            const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
+            const int head = TT / tph;
+            const int tt = TT - head * tph;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + mt * 16 + rg * 4 + i;
+                    const int pos = base_pos + min(row, p.M - 1);
+                    float v = rbf(acc[mt][nt][i]);
+                    int feat;
+                    if (kind != 2) {
+                        const float partner = __shfl_xor(v, 8, 64);
+                        const int j = tt * 8 + (c16 & 7);
+                        const float cs = bf2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
+                        const float sn = bf2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
+                        const float a = rbf(v * cs);
+                        const float b = rbf((c16 < 8 ? -partner : partner) * sn);
+                        v = rbf(a + b);
+                        feat = (c16 < 8) ? j : j + (hd >> 1);
+                    } else {
+                        feat = tt * 16 + c16;
+                    }
+                    if (row < p.M) {
+                        if (kind == 0) {
+                            p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2bf(v);
+                        } else {
+                            const int page = p.block_table[pos / p.page_size];
+                            const int slot = pos % p.page_size;
+                            const size_t hb = ((size_t)page * p.n_kv + head) * p.page_size * hd;
+                            if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2bf(v);        // K page  [slot][d]
+                            else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2bf(v);         // V^T page [d][slot]
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// xn[row] = weight * bf16(x * rsqrt(mean(x^2) + eps))   (LlamaRMSNorm, modeling_llama.py:62-67), one row per workgroup
+__global__ __launch_bounds__(256) void lsk_rmsnorm_rows_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w,
+                                                               float eps, int K, bf16_t* __restrict__ y, int ldy) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float ss = 0.f;
+    for (int k0 = tid * 8; k0 < K; k0 += 256 * 8) {
+        const bf16x8 v = *(const bf16x8*)(xr + k0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss = fmaf(f, f, ss); }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+    for (int k0 = tid * 8; k0 < K; k0 += 256 * 8) {
+        bf16x8 v = *(const bf16x8*)(xr + k0);
+        const bf16x8 g = *(const bf16x8*)(w + k0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(g[j]) * rbf(bf2f(v[j]) * inv));
+        *(bf16x8*)(y + (size_t)row * ldy + k0) = v;
+    }
+}

@@ -233,6 +233,12 @@ class HipEngine:
             m = min(_lib.LSK_MAX_ROWS, n - r0)
             self.run_layers(buffer, row_base + r0, m, pos_offset + r0, layer_begin, layer_end)
 
+    def run_bulk(self, n: int, layer_begin: int, layer_end: int) -> None:
+        check(self.lib.lsk_run_bulk(self._handle, n, layer_begin, layer_end, self._stream))
+
+    def set_option(self, option: int, value: int) -> None:
+        check(self.lib.lsk_engine_set_option(self._handle, option, value))
+
     def run_head(self, buffer: int, row_base: int, m: int, logits: Optional[torch.Tensor] = None,
                  want_tokens: bool = True) -> Optional[List[int]]:
         """logits: optional fp32 CUDA tensor [m, >=vocab] that receives the (bf16-rounded) logits."""

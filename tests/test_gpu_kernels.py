@@ -120,3 +120,29 @@ def test_accept_kernel(gpu_device, drafts, verified, eos, expect):
     vt = torch.tensor([verified[:td + 1]])
     ref_n = int(((~(dt == vt[:, :-1])).cumsum(dim=-1) < 1).sum().item())
     assert ref_n == n
+
+
+def test_prefill_kernels_match_decode_kernels(gpu_device):
+    """The MFMA-tiled prefill path (lsk_gemm_big + bulk RMSNorm) against 16-row passes of the decode
+    kernels on the same rows: same rounding points, different accumulation order -> equal up to rare
+    one-ulp bf16 flips in the hidden states."""
+    from layerskip_amd import _lib, synthetic
+    from layerskip_amd.engine import BUF_BULK, HipEngine
+    cfg = synthetic.make_config("tiny-gqa")
+    model = synthetic.build_model(cfg, seed=2, exit_layer=3, late_damping=0.1).to(gpu_device)
+    eng = HipEngine(model, max_ctx=512, max_prompt=300)
+    ids = synthetic.make_prompt(cfg.vocab_size, 203, 77)
+    outs = []
+    for threshold in (1 << 30, 1):
+        eng.set_option(_lib.LSK_OPT_BIG_THRESHOLD, threshold)
+        eng.reset()
+        eng.embed_rows(ids, BUF_BULK, 0)
+        eng.run_bulk(len(ids), 0, eng.num_layers)
+        outs.append(eng.read_rows(BUF_BULK, 0, len(ids)).float())
+    torch.cuda.synchronize()
+    a, b = outs
+    assert torch.isfinite(b).all()
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 0.03 * scale
+    assert (a - b).abs().mean().item() <= 0.004 * scale
+    eng.close()
