@@ -175,7 +175,8 @@ int lsk_write_rows(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, c
 int lsk_test_gemm(const void* x, int32_t m, int32_t k, const void* w_packed, int32_t n_rows,
                   const void* norm_w, float eps, float* y, int32_t target_wgs, void* stream);
 /* Longest-prefix acceptance on raw token arrays (device int32): the wavefront-ballot kernel
- * behind SSG:186-190.  result (device int32[2]) = {num_matches, num_drafts_effective}. */
+ * behind SSG:186-190.  result (device int32[64]) = {num_matches, num_drafts_effective, next_token, 0,
+ * emitted[17], drafts[16], verified[17]}.  num_drafts <= LSK_MAX_SPEC. */
 int lsk_test_accept(const int32_t* draft, const int32_t* verified, int32_t num_drafts,
                     const int32_t* eos, int32_t n_eos, int32_t* result, void* stream);
 /* Time `iters` back-to-back launches of the gate/up projection kernel of `layer` (the dominant

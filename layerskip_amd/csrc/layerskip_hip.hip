@@ -114,8 +114,14 @@ __global__ void lsk_argmax_finalize_kernel(const float* __restrict__ part_val, c
 // Greedy acceptance = longest matching prefix (SSG:186-190) as ONE wavefront: every lane compares one
 // draft position, __ballot gathers the mismatch mask, the count of leading matches is a find-first-set.
 // A drafted EOS ends the draft (SSG:146-148): positions after it do not count as drafts.
-// result: [0] num_matches, [1] num_drafts, [2] next_token, [3] new kv_len, [4..] emitted tokens
-__global__ void lsk_accept_kernel(const int* __restrict__ draft, const int* __restrict__ verified, int num_drafts,
+// result: [0] num_matches, [1] num_drafts, [2] next_token, [3] new kv_len, [4..21) emitted tokens,
+//         [21..37) the draft tokens, [37..54) the verified tokens  -- ONE device->host copy per step.
+// row_tokens[0] (= draft - 1) receives the next input token, so the following step needs no upload.
+#define LSK_RES_EMIT 4
+#define LSK_RES_DRAFT 21
+#define LSK_RES_VERIFIED 37
+#define LSK_RES_INTS 54
+__global__ void lsk_accept_kernel(int* __restrict__ draft, const int* __restrict__ verified, int num_drafts,
                                   const int* __restrict__ eos, int n_eos, int prompt_len, StepState* st,
                                   int* __restrict__ result) {
     const int lane = threadIdx.x;
@@ -123,15 +129,18 @@ __global__ void lsk_accept_kernel(const int* __restrict__ draft, const int* __re
     bool is_eos = false;
     if (lane < num_drafts) {
         d = draft[lane];
-        v = verified[lane];
         for (int i = 0; i < n_eos; ++i) is_eos |= (d == eos[i]);
     }
+    if (lane <= num_drafts) v = verified[lane];
     const unsigned long long eos_mask = __ballot(is_eos);
     const int td = eos_mask ? min(num_drafts, (int)__ffsll((long long)eos_mask)) : num_drafts;
     const unsigned long long mism = __ballot(lane < td && d != v) | (1ull << td);
     const int n = (int)__ffsll((long long)mism) - 1;
+    const int next = __shfl(v, n, 64);
+    if (lane < LSK_ROWS) result[LSK_RES_DRAFT + lane] = d;
+    if (lane <= LSK_ROWS) result[LSK_RES_VERIFIED + lane] = v;
+    if (lane < n) result[LSK_RES_EMIT + lane] = d;
     if (lane == 0) {
-        const int next = verified[n];
         result[0] = n;
         result[1] = td;
         result[2] = next;
@@ -140,10 +149,10 @@ __global__ void lsk_accept_kernel(const int* __restrict__ draft, const int* __re
             kv = st->kv_len + prompt_len + n;
             st->kv_len = kv;
             st->next_token = next;
+            draft[-1] = next;          // row_tokens[0]: input token of the next step
         }
         result[3] = kv;
-        for (int i = 0; i < n; ++i) result[4 + i] = draft[i];
-        result[4 + n] = next;
+        result[LSK_RES_EMIT + n] = next;
     }
 }
 
@@ -189,6 +198,9 @@ struct lsk_engine {
     int max_parts = 0;
     int n_pages = 0;
     int kv_len_host = 0;          // mirror of state->kv_len
+    int next_token_host = -1;     // mirror of row_tokens[0] after a step (-1: unknown)
+    int* host_result = nullptr;   // pinned [LSK_RES_INTS]
+    int eos_host[LSK_MAX_EOS]; int n_eos_host = -1;
     int target_wgs = 256;
     int big_threshold = 48;       // prompt rows from which the MFMA-tiled prefill kernels take over
     // profiling of the dominant kernel (gate/up projection)
@@ -231,7 +243,7 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.row_tokens = take(sizeof(int) * 32);
     L.verified = take(sizeof(int) * 32);
     L.eos = take(sizeof(int) * 16);
-    L.result = take(sizeof(int) * 32);
+    L.result = take(sizeof(int) * 64);
     L.bulk_ids = take(sizeof(int) * (size_t)(c->max_prompt + 16));
     L.part_val = take(sizeof(float) * 16 * (size_t)L.max_parts);
     L.part_idx = take(sizeof(int) * 16 * (size_t)L.max_parts);
@@ -288,7 +300,9 @@ static const size_t kMaxGemmLds = 160 * 1024;
 
 template <int PRO, int EPI>
 static int set_gemm_attr() {
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
     return 0;
 }
 
@@ -354,6 +368,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     hipError_t err = hipMemcpy(e->block_table, table.data(), sizeof(int) * L.n_pages, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
     if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
+    if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 64, hipHostMallocDefault);
     if (err != hipSuccess) { delete e; return lsk_fail("engine init copy failed: %s", hipGetErrorString(err)); }
     *out = e;
     return 0;
@@ -362,6 +377,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
 extern "C" int lsk_engine_destroy(lsk_engine* e) {
     if (!e) return 0;
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->host_result) (void)hipHostFree(e->host_result);
     delete e;
     return 0;
 }
@@ -441,7 +457,9 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
     const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
     if (lds > kMaxGemmLds) return lsk_fail("gemm LDS %zu exceeds %zu", lds, kMaxGemmLds);
-    hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+    if (p.M == 1) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+    else if (p.M <= 8) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 8>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+    else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 16>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     HIP_OK(hipGetLastError());
     if (grid_out) *grid_out = grid;
     return 0;
@@ -656,8 +674,16 @@ extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t pr
     LSK_TRY(check_ids(e, input_ids, P));
 
     if (P > 1) HIP_OK(hipMemcpyAsync(e->bulk_ids, input_ids, sizeof(int) * (P - 1), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
-    if (n_eos > 0) HIP_OK(hipMemcpyAsync(e->eos, eos_token_ids, sizeof(int) * n_eos, hipMemcpyHostToDevice, st));
+    if (input_ids[P - 1] != e->next_token_host) {   // otherwise the accept kernel already left it in row_tokens[0]
+        HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    if (n_eos != e->n_eos_host || (n_eos > 0 && memcmp(e->eos_host, eos_token_ids, sizeof(int) * n_eos) != 0)) {
+        if (n_eos > 0) {
+            HIP_OK(hipMemcpyAsync(e->eos, eos_token_ids, sizeof(int) * n_eos, hipMemcpyHostToDevice, st));
+            memcpy(e->eos_host, eos_token_ids, sizeof(int) * n_eos);
+        }
+        e->n_eos_host = n_eos;
+    }
 
     const int* kvp = &e->state->kv_len;
     // ---- forward_early over the prompt rows that are not the last one (LMU:213-276, rows 0..P-2) ----
@@ -679,22 +705,19 @@ extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t pr
     // ---- accept + rollback (SSG:186-221) ----
     hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, st, e->row_tokens + 1, e->verified, S, e->eos, n_eos, P, e->state, e->result);
     HIP_OK(hipGetLastError());
-    int host_res[4 + LSK_MAX_ROWS + 1];
-    int host_draft[LSK_MAX_ROWS + 1];
-    int host_ver[LSK_MAX_ROWS + 1];
-    HIP_OK(hipMemcpyAsync(host_res, e->result, sizeof(host_res), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(host_draft, e->row_tokens + 1, sizeof(int) * LSK_MAX_ROWS, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(host_ver, e->verified, sizeof(int) * (LSK_MAX_ROWS + 1), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(e->host_result, e->result, sizeof(int) * LSK_RES_INTS, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    const int* host_res = e->host_result;
     memset(out, 0, sizeof(*out));
     out->num_matches = host_res[0];
     out->num_drafts = host_res[1];
     out->num_emitted = host_res[0] + 1;
     out->next_token = host_res[2];
     out->kv_len = host_res[3];
-    for (int i = 0; i <= host_res[0]; ++i) out->emitted[i] = host_res[4 + i];
-    for (int i = 0; i < S; ++i) out->draft_tokens[i] = host_draft[i];
-    for (int i = 0; i <= S; ++i) out->verified_tokens[i] = host_ver[i];
+    for (int i = 0; i <= host_res[0]; ++i) out->emitted[i] = host_res[LSK_RES_EMIT + i];
+    for (int i = 0; i < S; ++i) out->draft_tokens[i] = host_res[LSK_RES_DRAFT + i];
+    for (int i = 0; i <= S; ++i) out->verified_tokens[i] = host_res[LSK_RES_VERIFIED + i];
+    e->next_token_host = host_res[2];
     e->kv_len_host = host_res[3];
     return 0;
 }
@@ -711,6 +734,7 @@ extern "C" int lsk_ar_step(lsk_engine* e, const int32_t* input_ids, int32_t n_id
     const int P = n_ids;
     if (P > 1) HIP_OK(hipMemcpyAsync(e->bulk_ids, input_ids, sizeof(int) * (P - 1), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
+    e->next_token_host = -1;
     const int* kvp = &e->state->kv_len;
     if (P > 1) {
         LSK_TRY(embed_rows_dev(e, e->bulk_ids, P - 1, e->hbulk, st));
@@ -811,8 +835,8 @@ extern "C" int lsk_test_gemm(const void* x, int32_t m, int32_t k, const void* w_
 extern "C" int lsk_test_accept(const int32_t* draft, const int32_t* verified, int32_t num_drafts, const int32_t* eos, int32_t n_eos,
                                int32_t* result, void* stream) {
     if (!draft || !verified || !result) return lsk_fail("lsk_test_accept: null pointer");
-    if (num_drafts < 0 || num_drafts > 63) return lsk_fail("lsk_test_accept: num_drafts %d out of range", num_drafts);
-    hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, draft, verified, num_drafts, eos, n_eos, 1,
+    if (num_drafts < 0 || num_drafts > LSK_MAX_SPEC) return lsk_fail("lsk_test_accept: num_drafts %d out of range", num_drafts);
+    hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)draft, verified, num_drafts, eos, n_eos, 1,
                        (StepState*)nullptr, result);
     HIP_OK(hipGetLastError());
     return 0;

@@ -57,30 +57,45 @@ __device__ __forceinline__ UnitInfo lsk_unit_info(int u, int units, int ntl, int
 __host__ __device__ inline int lsk_gemm_xstride(int K) { return (K < LSK_KC_ELEMS ? K : LSK_KC_ELEMS) * 2 + 16; }
 __host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS_X + (size_t)M * lsk_gemm_xstride(K); }
 
-template <int PRO>
-__device__ __forceinline__ void lsk_stage_chunk(const GemmParams& p, unsigned char* xs, int xstride, const float* inv,
-                                                int c, int steps_c, int tid) {
+// Activation staging is split in two so that no global load of x ever sits BEHIND the weight ring in a
+// wave's (in-order) load queue: `lsk_load_chunk` pulls this thread's 16-byte slice of every row of a
+// K-chunk into registers (issued before / under the weight stream), `lsk_store_chunk` applies the
+// RMSNorm (if any) and writes the bf16 rows to LDS later, without touching global memory.
+template <int PRO, int MB>
+__device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int steps_c, int tid, bf16x8 (&xr)[MB], bf16x8& nw) {
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
         const int k0 = c * LSK_KC_ELEMS + e0;
-        bf16x8 nw;
         if (PRO == PRO_RMS) nw = *(const bf16x8*)(p.norm_w + k0);
-        for (int r = 0; r < p.M; ++r) {
-            bf16x8 v = *(const bf16x8*)(p.x + (size_t)r * p.ldx + k0);
-            if (PRO == PRO_RMS) {
-                const float s = inv[r];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xn = rbf(bf2f(v[j]) * s);           // x32 * rsqrt(var + eps) -> model dtype
-                    v[j] = f2bf(bf2f(nw[j]) * xn);                   // weight * that, rounded again
+        for (int i = 0; i < MB; ++i) xr[i] = *(const bf16x8*)(p.x + (size_t)min(i, p.M - 1) * p.ldx + k0);
+    }
+}
+
+template <int PRO, int MB>
+__device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned char* xs, int xstride, const float* inv,
+                                                int steps_c, int tid, const bf16x8 (&xr)[MB], const bf16x8& nw) {
+    const int e0 = tid * 8;
+    if (e0 < steps_c * 32) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            if (i < p.M) {
+                bf16x8 v = xr[i];
+                if (PRO == PRO_RMS) {
+                    const float s = inv[i];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xn = rbf(bf2f(v[j]) * s);           // x32 * rsqrt(var + eps) -> model dtype
+                        v[j] = f2bf(bf2f(nw[j]) * xn);                   // weight * that, rounded again
+                    }
                 }
+                *(bf16x8*)(xs + (size_t)i * xstride + e0 * 2) = v;
             }
-            *(bf16x8*)(xs + (size_t)r * xstride + e0 * 2) = v;
         }
     }
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, int MB>
 __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* slab = (float*)(smem + LSK_LDS_SLAB);
@@ -101,26 +116,39 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
 
-    // ---- fill the weight ring before touching the activations: HBM latency hides the prologue ----
-    u32x4 ring[LSK_SPW];
+    // ---- activations first (they must not queue behind the weight ring), then fill the ring ----
     UnitInfo cur = lsk_unit_info(0, units, ntl, ksteps, tile0, w, lane);
+    bf16x8 xr[MB];
+    bf16x8 nw;
+    float ss[MB];
+    if (PRO == PRO_RMS) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) ss[i] = 0.f;
+        // RMSNorm statistics need whole rows: walk the K-chunks last-to-first so chunk 0 stays in xr
+        for (int c = nchunks - 1; c >= 0; --c) {
+            const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
+            lsk_load_chunk<PRO, MB>(p, c, steps_c, tid, xr, nw);
+            if (tid * 8 < steps_c * 32) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = bf2f(xr[i][j]); ss[i] = fmaf(f, f, ss[i]); }
+            }
+        }
+    } else {
+        lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
+    }
+    u32x4 ring[LSK_SPW];
 #pragma unroll
     for (int s = 0; s < LSK_SPW; ++s) {
         const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
         ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
     }
-
-    // ---- activation prologue: RMSNorm statistics (fp32, fixed order), then stage K-chunk 0 ----
     if (PRO == PRO_RMS) {
-        for (int r = 0; r < M; ++r) {
-            float ss = 0.f;
-            for (int k0 = tid * 8; k0 < p.K; k0 += LSK_KC_ELEMS) {
-                const bf16x8 v = *(const bf16x8*)(p.x + (size_t)r * p.ldx + k0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss = fmaf(f, f, ss); }
-            }
-            ss = wave_sum(ss);
-            if (lane == 0) red[r * LSK_WAVES + w] = ss;
+        for (int i = 0; i < MB; ++i) {
+            const float t = wave_sum(ss[i]);
+            if (lane == 0 && i < M) red[i * LSK_WAVES + w] = t;
         }
         __syncthreads();
         if (tid < M) {
@@ -131,7 +159,8 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
         }
         __syncthreads();
     }
-    lsk_stage_chunk<PRO>(p, xs, xstride, inv, 0, cur.steps_c, tid);
+    lsk_store_chunk<PRO, MB>(p, xs, xstride, inv, cur.steps_c, tid, xr, nw);
+    if (nchunks > 1) lsk_load_chunk<PRO, MB>(p, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);   // prefetch chunk 1
     __syncthreads();
 
     const int arow = min(lane & 15, M - 1);
@@ -143,8 +172,11 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
     for (int u = 0; u < units; ++u) {
         const UnitInfo nxt = lsk_unit_info(u + 1, units, ntl, ksteps, tile0, w, lane);
         if (nchunks > 1 && cur.tl == 0 && u > 0) {
-            // every wave passed the previous unit's barrier => nobody still reads the old chunk
-            lsk_stage_chunk<PRO>(p, xs, xstride, inv, cur.c, cur.steps_c, tid);
+            // every wave passed the previous unit's barrier => nobody still reads the old chunk; the rows
+            // of this chunk were prefetched into xr one chunk ago, the next chunk's are requested now
+            lsk_store_chunk<PRO, MB>(p, xs, xstride, inv, cur.steps_c, tid, xr, nw);
+            if (cur.c + 1 < nchunks)
+                lsk_load_chunk<PRO, MB>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
             __syncthreads();
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -1,0 +1,50 @@
+"""GPU micro-benchmark (not a test): skinny projection kernel bandwidth vs shape / M / grid size."""
+import ctypes
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from layerskip_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+
+
+def run(k, n, m, wgs, with_norm, nbuf=6, iters=60):
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.lsk_packed_bytes(n, k, ctypes.byref(nbytes)))
+    bufs = [torch.randint(0, 255, (nbytes.value,), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    for b in bufs:  # keep bf16 values finite-ish: clear exponent top bits
+        b.view(torch.int16).bitwise_and_(0x3FFF)
+    x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+    nw = torch.ones(k, device=dev, dtype=torch.bfloat16)
+    y = torch.empty(m, n, dtype=torch.float32, device=dev)
+    def launch(i):
+        _lib.check(lib.lsk_test_gemm(x.data_ptr(), m, k, bufs[i % nbuf].data_ptr(), n, nw.data_ptr() if with_norm else None,
+                                     1e-5, y.data_ptr(), wgs, st()))
+    for i in range(nbuf):
+        launch(i)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(iters):
+        launch(i)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / iters
+    return us, nbytes.value / us / 1e3   # us, GB/s
+
+
+shapes = {"qkv": (4096, 12288, True), "o": (4096, 4096, False), "gateup": (4096, 22016, True), "down": (11008, 4096, False),
+          "head": (4096, 32000, True)}
+which = sys.argv[1:] or list(shapes)
+for name in which:
+    k, n, norm = shapes[name]
+    for m in (1, 7):
+        row = []
+        for wgs in (128, 192, 256, 384, 512, 768, 1024):
+            us, gbs = run(k, n, m, wgs, norm)
+            row.append(f"{wgs}:{us:6.1f}us/{gbs:5.0f}")
+        print(f"{name:7s} M={m}  " + "  ".join(row), flush=True)

@@ -107,7 +107,7 @@ def test_accept_kernel(gpu_device, drafts, verified, eos, expect):
     d = torch.tensor(drafts + [0], dtype=torch.int32, device=gpu_device)
     v = torch.tensor(verified, dtype=torch.int32, device=gpu_device)
     e = torch.tensor(eos + [0], dtype=torch.int32, device=gpu_device)
-    res = torch.full((32,), -1, dtype=torch.int32, device=gpu_device)
+    res = torch.full((64,), -1, dtype=torch.int32, device=gpu_device)
     L.check(lib.lsk_test_accept(d.data_ptr(), v.data_ptr(), len(drafts), e.data_ptr(), len(eos), res.data_ptr(), _stream()))
     torch.cuda.synchronize()
     r = res.tolist()
