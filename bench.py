@@ -153,10 +153,15 @@ def main():
         back_to_back_ms = engine.time_gateup(0, 1, 64)
         avg_ms = ms / max(1, launches)
         achieved = pb["gate_up"] / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gateup.json")
+        if args.model == "llama2-7B" and os.path.exists(pmc):
+            # HBM bytes per launch from the PMC passes (cannot be collected live inside the timed run)
+            traffic = json.load(open(pmc))["hbm_read_bytes_per_launch"]
         out["roofline"] = {
             "kernel": "lsk_gemm_kernel<PRO_RMS,EPI_SWIGLU> (post-attn RMSNorm + gate/up + SiLU*mul)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_launch": pb["gate_up"], "avg_launch_ms": round(avg_ms, 5), "launches_timed": launches,
             "back_to_back_launch_ms": round(back_to_back_ms, 5),
         }
