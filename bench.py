@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--late-damping", type=float, default=0.03)
     ap.add_argument("--strategy", default="self_speculative", choices=["self_speculative", "autoregressive"])
     ap.add_argument("--target-wgs", type=int, default=0)
+    ap.add_argument("--parallelism", default="replica", choices=["replica", "pp"],
+                    help="multi-GPU mode: one replica per GPU on independent prompts (default), or the "
+                         "layer-range pipeline of layerskip_amd/pipeline.py (capacity mode, one sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-new-tokens", type=int, default=16)
     ap.add_argument("--cpu-prompt-len", type=int, default=64)
@@ -85,6 +88,8 @@ def main():
     E = args.exit_layer or synthetic.default_exit_layer(args.model)
     S = args.num_speculations or synthetic.default_num_speculations(args.model)
     cfg = synthetic.make_config(args.model)
+    if args.parallelism == "pp" and world > 1:
+        return pipeline_bench(args, cfg, E, S, rank, world, dev)
     t0 = time.time()
     model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=args.late_damping, dtype=torch.bfloat16,
                                   device=dev, gen_device=dev)
@@ -187,6 +192,49 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pipeline_bench(args, cfg, E, S, rank, world, dev):
+    """Layer-range pipeline over RCCL point-to-point: every rank materialises and packs only its layers."""
+    import torch.distributed as dist
+    from layerskip_amd.engine import HipEngine
+    from layerskip_amd.pipeline import PipelineSpeculativeDecoder, plan_partition
+    part = plan_partition(cfg.num_hidden_layers, E, world)
+    model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=args.late_damping, dtype=torch.bfloat16,
+                                  device=dev, gen_device=dev, layer_range=part[rank])
+    engine = HipEngine(model, max_ctx=args.prompt_len + args.max_steps + S + 16, max_prompt=args.prompt_len,
+                       target_wgs=args.target_wgs, layer_range=part[rank])
+    dec = PipelineSpeculativeDecoder(engine, rank, world, part, E)
+    eos = [cfg.vocab_size]
+
+    def one(i):
+        prompt = synthetic.make_prompt(cfg.vocab_size, args.prompt_len, i) if rank == 0 else None
+        return dec.generate(prompt, eos, args.max_steps, S)
+
+    for i in range(args.warmup):
+        one(1000 + i)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results = [one(i) for i in range(args.steps)]
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        tokens = sum(len(r.predicted_tokens) for r in results)
+        acc = [r.acceptance_rate for r in results if r.acceptance_rate is not None]
+        elapsed = float(t.item())
+        print(json.dumps({
+            "metric": "decoded tokens/sec (self-speculative, greedy)", "value": round(tokens / elapsed, 2), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / max(1, args.steps), 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "acceptance_rate": round(sum(acc) / len(acc), 4) if acc else None,
+            "config": {"workload": f"{args.model} shape, exit_layer={E}, num_speculations={S}, {args.prompt_len}-token prompt, "
+                                   f"{args.max_steps} new tokens, batch 1, greedy, random-init weights (late damping {args.late_damping})",
+                       "strategy": "self_speculative", "parallelism": f"pp{world} layer ranges {part}"}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _trace_steps(strategy, model, prompt, eos, gen):

@@ -1,0 +1,44 @@
+"""Speculative vs autoregressive equality check, the reference's own parity definition
+(reference correctness.py:38-99) at token-id level: for every sample both strategies decode greedily and the
+outputs must be identical (`--sample False`, README.md:145-156).  Exit code 1 on any mismatch."""
+from __future__ import annotations
+
+import json
+import sys
+from dataclasses import replace
+
+import torch
+import transformers
+
+from layerskip_amd import GenerationConfig, TokenGenerator
+from layerskip_amd.cli.common import Arguments, SyntheticArguments, load_model_and_tokenizer, make_strategy
+from benchmark import BenchmarkArguments, load_prompts
+
+
+def main():
+    parser = transformers.HfArgumentParser((Arguments, BenchmarkArguments, GenerationConfig, SyntheticArguments))
+    args, b, gen, syn = parser.parse_args_into_dataclasses(return_remaining_strings=False)
+    torch.manual_seed(0)                                          # correctness.py:38-41 seeds with 0
+    gen = replace(gen, sample=False)
+    model, tokenizer = load_model_and_tokenizer(args, syn, gen.exit_layer)
+    spec_cfg = replace(gen, generation_strategy="self_speculative")
+    ar_cfg = replace(gen, generation_strategy="autoregressive", exit_layer=-1)
+    spec = TokenGenerator(tokenizer, model, make_strategy(spec_cfg))
+    ar = TokenGenerator(tokenizer, model, make_strategy(ar_cfg))
+    eos = [model.config.vocab_size] if tokenizer is None else [tokenizer.eos_token_id]
+    errors = 0
+    prompts = load_prompts(b, model.config.vocab_size, syn.prompt_len, args.seed)
+    for i, ids in enumerate(prompts):
+        a = spec.generate_from_ids(ids, eos, spec_cfg).generation_strategy_result.predicted_tokens
+        r = ar.generate_from_ids(ids, eos, ar_cfg).generation_strategy_result.predicted_tokens
+        if a != r:
+            errors += 1
+            first = next((k for k, (x, y) in enumerate(zip(a, r)) if x != y), min(len(a), len(r)))
+            print(f"sample {i}: mismatch at token {first}")
+    out = {"errors": errors, "error_pct": errors / max(1, len(prompts)), "num_samples": len(prompts)}
+    print(json.dumps(out))
+    sys.exit(1 if errors else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -191,6 +191,8 @@ struct lsk_engine {
     bf16_t* attn = nullptr;       // [16][n_heads*hd]
     bf16_t* act = nullptr;        // [16][I]
     float* attn_part = nullptr;   // [n_heads][n_pages][16][hd + 2] split-KV partials
+    int* attn_cnt = nullptr;      // [n_heads] arrival tickets of the in-launch combine
+    bool fused_attn = true;
     bf16_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]
     bf16_t* kv_pool = nullptr;
     size_t kv_layer_elems = 0;    // elements per layer (K and V)
@@ -213,7 +215,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
     size_t state, zero, block_table, row_tokens, verified, eos, result, bulk_ids, part_val, part_idx, hrow, hbulk, qbuf,
-        attn, act, attn_part, xn_bulk, q_bulk, attn_bulk, act_bulk, total;
+        attn, act, attn_part, attn_cnt, xn_bulk, q_bulk, attn_bulk, act_bulk, total;
     int max_parts, n_pages;
 };
 
@@ -253,6 +255,7 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.attn = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
     L.act = take(2 * (size_t)LSK_MAX_ROWS * c->intermediate);
     L.attn_part = take(sizeof(float) * (size_t)c->n_heads * L.n_pages * LSK_MAX_ROWS * (c->head_dim + 2));
+    L.attn_cnt = take(sizeof(int) * (size_t)c->n_heads);
     L.xn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->hidden);
     L.q_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
     L.attn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
@@ -352,6 +355,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->attn = (bf16_t*)(e->ws + L.attn);
     e->act = (bf16_t*)(e->ws + L.act);
     e->attn_part = (float*)(e->ws + L.attn_part);
+    e->attn_cnt = (int*)(e->ws + L.attn_cnt);
     e->xn_bulk = (bf16_t*)(e->ws + L.xn_bulk);
     e->q_bulk = (bf16_t*)(e->ws + L.q_bulk);
     e->attn_bulk = (bf16_t*)(e->ws + L.attn_bulk);
@@ -368,6 +372,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     hipError_t err = hipMemcpy(e->block_table, table.data(), sizeof(int) * L.n_pages, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
     if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
+    if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * cfg->n_heads);
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 64, hipHostMallocDefault);
     if (err != hipSuccess) { delete e; return lsk_fail("engine init copy failed: %s", hipGetErrorString(err)); }
     *out = e;
@@ -419,6 +424,7 @@ static int set_kv_len(lsk_engine* e, int kv_len, bool add, hipStream_t st) {
 
 extern "C" int lsk_engine_reset(lsk_engine* e, void* stream) {
     if (!e) return lsk_fail("null engine");
+    HIP_OK(hipMemsetAsync(e->attn_cnt, 0, sizeof(int) * e->cfg.n_heads, (hipStream_t)stream));
     return set_kv_len(e, 0, false, (hipStream_t)stream);
 }
 
@@ -439,8 +445,13 @@ extern "C" int lsk_engine_get_kv_len(lsk_engine* e, int32_t* kv_len) {
 static int ready(lsk_engine* e) {
     if (!e) return lsk_fail("null engine");
     if (!e->embed) return lsk_fail("engine globals not bound (lsk_engine_set_globals)");
-    for (size_t i = 0; i < e->layers.size(); ++i)
-        if (!e->layers[i].wqkv) return lsk_fail("layer %zu not bound (lsk_engine_set_layer)", i);
+    return 0;
+}
+
+// A pipeline rank binds only its own layer range: every entry point checks the range it touches.
+static int layers_bound(lsk_engine* e, int lb, int le) {
+    for (int i = lb; i < le; ++i)
+        if (!e->layers[i].wqkv) return lsk_fail("layer %d not bound on this engine (lsk_engine_set_layer)", i);
     return 0;
 }
 
@@ -486,6 +497,7 @@ static int launch_attn(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t
     sp.n_kv = c.n_kv_heads; sp.group = c.n_heads / c.n_kv_heads; sp.M = m; sp.kv_len = &e->state->kv_len; sp.pos_off = pos_off;
     sp.scale_log2e = (float)((1.0 / sqrt((double)hd)) * 1.4426950408889634);
     sp.part = e->attn_part; sp.max_pages = e->n_pages;
+    sp.counters = e->fused_attn ? e->attn_cnt : nullptr; sp.out = out; sp.ldo = qdim;
     const int last_pos = e->kv_len_host + pos_off + m - 1;
     const int pages = last_pos / LSK_ATTN_PAGE + 1;
     if (pages > e->n_pages) return lsk_fail("attention reaches page %d of %d", pages, e->n_pages);
@@ -493,6 +505,7 @@ static int launch_attn(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t
     if (hd == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, sp);
     else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, sp);
     HIP_OK(hipGetLastError());
+    if (e->fused_attn) return 0;
     AttnCombineParams cp{};
     cp.part = e->attn_part; cp.max_pages = e->n_pages; cp.M = m; cp.kv_len = &e->state->kv_len; cp.pos_off = pos_off;
     cp.out = out; cp.ldo = qdim;
@@ -667,6 +680,7 @@ extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t pr
     if (P < 1 || P - 1 > c.max_prompt) return lsk_fail("prompt_len %d out of range (max_prompt %d)", P, c.max_prompt);
     if (S < 0 || S > LSK_MAX_SPEC) return lsk_fail("num_speculations %d out of range 0..%d", S, LSK_MAX_SPEC);
     if (E < 1 || E > L) return lsk_fail("exit_layer %d out of range 1..%d", E, L);
+    LSK_TRY(layers_bound(e, 0, L));
     if (n_eos < 0 || n_eos > LSK_MAX_EOS) return lsk_fail("n_eos %d out of range 0..%d", n_eos, LSK_MAX_EOS);
     if (n_eos > 0 && !eos_token_ids) return lsk_fail("null eos_token_ids");
     const int C = e->kv_len_host;
@@ -729,6 +743,7 @@ extern "C" int lsk_ar_step(lsk_engine* e, const int32_t* input_ids, int32_t n_id
     if (!input_ids || !next_token) return lsk_fail("lsk_ar_step: null pointer");
     if (n_ids < 1 || n_ids - 1 > c.max_prompt) return lsk_fail("n_ids %d out of range", n_ids);
     if (layer_end < 1 || layer_end > c.num_layers) return lsk_fail("layer_end %d out of range", layer_end);
+    LSK_TRY(layers_bound(e, 0, layer_end));
     if (e->kv_len_host + n_ids > c.max_ctx) return lsk_fail("context overflow");
     LSK_TRY(check_ids(e, input_ids, n_ids));
     const int P = n_ids;
@@ -768,6 +783,7 @@ extern "C" int lsk_run_layers(lsk_engine* e, int32_t buffer, int32_t row_base, i
     LSK_TRY(check_rows(e, buffer, row_base, m));
     if (layer_begin < 0 || layer_end > e->cfg.num_layers || layer_begin > layer_end) return lsk_fail("bad layer range [%d,%d)", layer_begin, layer_end);
     if (pos_offset < 0 || e->kv_len_host + pos_offset + m > e->cfg.max_ctx) return lsk_fail("positions exceed max_ctx");
+    LSK_TRY(layers_bound(e, layer_begin, layer_end));
     return run_layers(e, buf_rows(e, buffer, row_base), m, &e->state->kv_len, pos_offset, layer_begin, layer_end, (hipStream_t)stream);
 }
 
@@ -776,6 +792,7 @@ extern "C" int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32
     if (n < 1 || n > e->cfg.max_prompt + 16) return lsk_fail("lsk_run_bulk: %d rows out of range", n);
     if (layer_begin < 0 || layer_end > e->cfg.num_layers || layer_begin > layer_end) return lsk_fail("bad layer range [%d,%d)", layer_begin, layer_end);
     if (e->kv_len_host + n > e->cfg.max_ctx) return lsk_fail("positions exceed max_ctx");
+    LSK_TRY(layers_bound(e, layer_begin, layer_end));
     return run_bulk(e, n, &e->state->kv_len, layer_begin, layer_end, (hipStream_t)stream);
 }
 
@@ -784,6 +801,7 @@ extern "C" int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t valu
     switch (option) {
         case LSK_OPT_BIG_THRESHOLD: e->big_threshold = value; return 0;
         case LSK_OPT_TARGET_WGS: e->target_wgs = value > 0 ? value : 256; return 0;
+        case LSK_OPT_FUSED_ATTN: e->fused_attn = value != 0; return 0;
         default: return lsk_fail("unknown option %d", option);
     }
 }
@@ -845,6 +863,7 @@ extern "C" int lsk_test_accept(const int32_t* draft, const int32_t* verified, in
 extern "C" int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t iters, float* ms_per_launch, void* stream) {
     LSK_TRY(ready(e));
     if (layer < 0 || layer >= e->cfg.num_layers || m < 1 || m > LSK_MAX_ROWS || iters < 1 || !ms_per_launch) return lsk_fail("lsk_time_gateup: bad arguments");
+    LSK_TRY(layers_bound(e, 0, e->cfg.num_layers));
     hipStream_t st = (hipStream_t)stream;
     const lsk_config& c = e->cfg;
     hipEvent_t a, b;

@@ -43,6 +43,9 @@ struct AttnSplitParams {
     float scale_log2e;      // head_dim^-0.5 * log2(e)
     float* part;            // [n_heads][max_pages][16][HD + 2]
     int max_pages;
+    int* counters;          // [n_heads] arrival tickets (self-resetting); nullptr = separate combine kernel
+    bf16_t* out;            // [M][ldo] attention output (written by the last-arriving page of a head)
+    int ldo;
 };
 
 struct AttnCombineParams {
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const 
     const int base_pos = *p.kv_len + p.pos_off;
     const int M = p.M;
     const int key0 = page_l * LSK_ATTN_PAGE;
-    if (key0 > base_pos + M - 1) return;     // page entirely in the future of every row
+    const bool fused = p.counters != nullptr;
+    if (key0 > base_pos + M - 1 && !fused) return;     // page entirely in the future of every row
 
     // ---- every load of this wave up front ----
     const int page = p.block_table[page_l];
@@ -163,8 +167,56 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const 
                 v += src[d] * __builtin_amdgcn_exp2f(src[HD] - m);      // d == HD + 1: the running sum l
             }
         }
-        p.part[(((size_t)head * p.max_pages + page_l) * LSK_ROWS + r) * PSTRIDE + d] = v;
+        float* dstp = p.part + (((size_t)head * p.max_pages + page_l) * LSK_ROWS + r) * PSTRIDE + d;
+        if (fused) __hip_atomic_store(dstp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+        else *dstp = v;
     }
+    if (!fused) return;
+    // ---- in-launch combine by the LAST page-workgroup of this head to arrive -------------------------
+    // Publish = write-through (sc1) partial stores, drained by every storing wave, then ONE relaxed
+    // agent-scope ticket; the last arriver reads all partials with sc1 loads (they bypass its L1 and the
+    // data was written through to memory, so no fence is needed on either side) and combines them in page
+    // order -- placement- and arrival-order independent, bit-identical to the two-kernel form.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(p.counters + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == (int)gridDim.y - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
+    for (int e = tid; e < M * HD; e += LSK_ATTN_THREADS) {
+        const int r = e / HD;
+        const int d = e - r * HD;
+        const int n_pages = (base_pos + r) / LSK_ATTN_PAGE + 1;
+        float m = LSK_ATTN_NEG, l = 0.f, a = 0.f;
+        for (int p0 = 0; p0 < n_pages; p0 += 8) {
+            float mo[8], lo[8], ao[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pg = min(p0 + i, n_pages - 1);
+                const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
+                mo[i] = __hip_atomic_load(src + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo[i] = __hip_atomic_load(src + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ao[i] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (p0 + i < n_pages) {
+                    const float mn = fmaxf(m, mo[i]);
+                    const float fa = __builtin_amdgcn_exp2f(m - mn);
+                    const float fb = __builtin_amdgcn_exp2f(mo[i] - mn);
+                    l = l * fa + lo[i] * fb;
+                    a = a * fa + ao[i] * fb;
+                    m = mn;
+                }
+            }
+        }
+        p.out[(size_t)r * p.ldo + head * HD + d] = f2bf(a / l);
+    }
+    if (tid == 0) __hip_atomic_store(p.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int HD>

@@ -50,7 +50,7 @@ class HipEngine:
     """One engine per (model, device).  Not re-entrant; one caller thread (like the reference)."""
 
     def __init__(self, model, max_ctx: int = 2048, max_prompt: int = 1024, page_size: int = 128,
-                 target_wgs: int = 0):
+                 target_wgs: int = 0, layer_range: Optional[Sequence[int]] = None):
         self.lib = _lib.load()
         cfg = model.config
         weight = model.model.embed_tokens.weight
@@ -71,8 +71,9 @@ class HipEngine:
         self.vocab = cfg.vocab_size
         self.page_size = page_size
         self.target_wgs = target_wgs
+        self.layer_range = tuple(layer_range) if layer_range is not None else (0, self.num_layers)
         self._handle = ctypes.c_void_p(None)
-        self._packed = []           # per-layer packed buffers (kept alive)
+        self._packed = []           # per-layer packed buffers (kept alive); None outside layer_range
         self._globals = {}
         self._buffers = {}
         with torch.cuda.device(self.device):
@@ -102,7 +103,10 @@ class HipEngine:
         m = self.model
         hd, H, I = self.head_dim, self.hidden, self.intermediate
         qdim, kvdim = self.n_heads * hd, self.n_kv_heads * hd
-        for layer in m.model.layers:
+        for idx, layer in enumerate(m.model.layers):
+            if not (self.layer_range[0] <= idx < self.layer_range[1]):
+                self._packed.append(None)       # another pipeline rank owns this layer
+                continue
             a, mlp = layer.self_attn, layer.mlp
             wqkv = self._packed_buffer(qdim + 2 * kvdim, H)
             self._pack_into(wqkv, a.q_proj.weight, 0, 1, hd)
@@ -159,7 +163,10 @@ class HipEngine:
         check(self.lib.lsk_engine_create(ctypes.byref(self.cfg), self._buffers["ws"].data_ptr(), ws.value,
                                          self._buffers["kv"].data_ptr(), kv.value, ctypes.byref(handle)))
         self._handle = handle
-        for i, (wqkv, wo, wgu, wdown, n1, n2) in enumerate(self._packed):
+        for i, packed in enumerate(self._packed):
+            if packed is None:
+                continue
+            wqkv, wo, wgu, wdown, n1, n2 = packed
             check(self.lib.lsk_engine_set_layer(handle, i, wqkv.data_ptr(), wo.data_ptr(), wgu.data_ptr(),
                                                 wdown.data_ptr(), n1.data_ptr(), n2.data_ptr()))
         g = self._globals

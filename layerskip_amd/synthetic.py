@@ -120,14 +120,15 @@ def build_model(
     device: str | torch.device = "cpu",
     gen_device: Optional[str | torch.device] = None,
     init_std: float = 0.02,
+    layer_range: Optional[tuple] = None,
 ) -> transformers.LlamaForCausalLM:
     """Random-init ``LlamaForCausalLM`` with reproducible weights.
 
     Every parameter is drawn from its own generator (seed, parameter index), in fp32,
     ``normal(0, init_std)`` for matrices and ``1 + 0.1*normal`` for RMSNorm gains, then
     ``o_proj`` / ``down_proj`` of layers ``>= exit_layer`` are multiplied by
-    ``late_damping`` and everything is cast to ``dtype``.  ``gen_device`` chooses where
-    the random numbers are drawn: "cpu" (default; bit-reproducible everywhere, used by
+    ``late_damping`` and everything is cast to ``dtype``.  ``layer_range`` materialises only
+    decoder layers [a, b) (pipeline ranks).  ``gen_device`` chooses where the random numbers are drawn: "cpu" (default; bit-reproducible everywhere, used by
     the golden fixtures) or the GPU (fast path for 7B+ shapes in bench.py).
     """
     device = torch.device(device)
@@ -140,6 +141,9 @@ def build_model(
     for index, (name, param) in enumerate(named):
         if tied and name == "lm_head.weight":
             continue
+        if layer_range is not None and name.startswith("model.layers."):
+            if not (layer_range[0] <= int(name.split(".")[2]) < layer_range[1]):
+                continue        # stays on the meta device: a pipeline rank only materialises its own layers
         g = _param_generator(seed, index, gen_device)
         shape = tuple(param.shape)
         if param.dim() == 1:

@@ -1,0 +1,93 @@
+"""CPU stand-in for HipEngine's building-block API (tests only): same calls, arithmetic from the
+reference-pinned oracle in fp32, a rank only owns layers [lb, le).  Used to run the multi-rank pipeline
+protocol of layerskip_amd/pipeline.py over gloo without a GPU."""
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from oracle import llama_oracle as lo
+
+
+class CpuStageBackend:
+    def __init__(self, model, layer_range=None, max_rows=4096):
+        self.om = lo.OracleModel.from_hf(model, dtype=torch.float32) if layer_range is None else None
+        self.model = model
+        self.num_layers = model.config.num_hidden_layers
+        self.hidden = model.config.hidden_size
+        self.vocab = model.config.vocab_size
+        self.device = torch.device("cpu")
+        self.lb, self.le = layer_range if layer_range is not None else (0, self.num_layers)
+        if self.om is None:
+            self.om = self._partial_oracle(model)
+        self.buf = {0: torch.zeros(16, self.hidden), 1: torch.zeros(max_rows, self.hidden)}
+        self.kv = [None] * self.num_layers
+        self._kv_len = 0
+
+    def _partial_oracle(self, model):
+        # only this rank's layers are materialised; borrow them, leave the rest as None
+        cfg = model.config
+        layers = []
+        for i, layer in enumerate(model.model.layers):
+            if self.lb <= i < self.le:
+                a, m = layer.self_attn, layer.mlp
+                f = lambda t: t.detach().float()
+                layers.append(lo.LayerWeights(f(layer.input_layernorm.weight), f(a.q_proj.weight), f(a.k_proj.weight),
+                                              f(a.v_proj.weight), f(a.o_proj.weight), f(layer.post_attention_layernorm.weight),
+                                              f(m.gate_proj.weight), f(m.up_proj.weight), f(m.down_proj.weight)))
+            else:
+                layers.append(None)
+        rot = model.model.rotary_emb
+        hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        return lo.OracleModel(embed=model.model.embed_tokens.weight.detach().float(), layers=layers,
+                              final_norm=model.model.norm.weight.detach().float(), lm_head=model.lm_head.weight.detach().float(),
+                              inv_freq=rot.inv_freq.detach().float().clone(), attention_scaling=float(rot.attention_scaling),
+                              n_heads=cfg.num_attention_heads, n_kv_heads=cfg.num_key_value_heads, head_dim=hd,
+                              eps=float(cfg.rms_norm_eps), attn_impl="sdpa", dtype=torch.float32)
+
+    # ---- state
+    def reset(self):
+        self.kv = [None] * self.num_layers
+        self._kv_len = 0
+
+    @property
+    def kv_len(self):
+        return self._kv_len
+
+    def set_kv_len(self, n):
+        self._kv_len = n
+
+    # ---- building blocks
+    def embed_rows(self, ids: Sequence[int], buffer: int, row_base: int):
+        self.buf[buffer][row_base:row_base + len(ids)] = F.embedding(torch.tensor(list(ids)), self.om.embed)
+
+    def run_layers(self, buffer, row_base, m, pos_offset, layer_begin, layer_end):
+        base = self._kv_len + pos_offset
+        h = self.buf[buffer][row_base:row_base + m].unsqueeze(0)
+        pos = torch.arange(base, base + m).unsqueeze(0)
+        mask = lo.decoder_mask(m, base + m, h.dtype, base)
+        with torch.inference_mode():
+            for l in range(layer_begin, layer_end):
+                assert self.lb <= l < self.le, f"layer {l} is not owned by this rank"
+                past = None
+                if self.kv[l] is not None and base > 0:
+                    past = (self.kv[l][0][:, :, :base], self.kv[l][1][:, :, :base])
+                h, kv = lo.decoder_layer(self.om, self.om.layers[l], h, mask, pos, past)
+                self.kv[l] = kv
+        self.buf[buffer][row_base:row_base + m] = h[0]
+
+    def run_bulk(self, n, layer_begin, layer_end):
+        self.run_layers(1, 0, n, 0, layer_begin, layer_end)
+
+    def run_head(self, buffer, row_base, m, logits=None, want_tokens=True) -> Optional[List[int]]:
+        with torch.inference_mode():
+            lg = lo.head(self.om, self.buf[buffer][row_base:row_base + m].unsqueeze(0))[0]
+        if logits is not None:
+            logits[:m, : self.vocab] = lg
+        return lg.argmax(-1).tolist() if want_tokens else None
+
+    def read_rows(self, buffer, row_base, m):
+        return self.buf[buffer][row_base:row_base + m].to(torch.bfloat16).clone()
+
+    def write_rows(self, buffer, row_base, rows):
+        self.buf[buffer][row_base:row_base + rows.shape[0]] = rows.float()

@@ -146,3 +146,29 @@ def test_prefill_kernels_match_decode_kernels(gpu_device):
     assert (a - b).abs().max().item() <= 0.03 * scale
     assert (a - b).abs().mean().item() <= 0.004 * scale
     eng.close()
+
+
+def test_fused_attention_combine_equals_two_kernel_form(gpu_device):
+    """In-launch last-arriver combine (write-through partials + ticket) vs the separate combine kernel:
+    bit-identical hidden states, for decode rows and a verify block, under repeated launches."""
+    from layerskip_amd import _lib, synthetic
+    from layerskip_amd.engine import BUF_BULK, BUF_STEP, HipEngine
+    cfg = synthetic.make_config("tiny-gqa")
+    model = synthetic.build_model(cfg, seed=4, exit_layer=3, late_damping=0.1).to(gpu_device)
+    eng = HipEngine(model, max_ctx=1024, max_prompt=600)
+    ids = synthetic.make_prompt(cfg.vocab_size, 530, 5)
+    outs = []
+    for fused in (0, 1):
+        eng.set_option(_lib.LSK_OPT_FUSED_ATTN, fused)
+        eng.reset()
+        eng.embed_rows(ids[:-9], BUF_BULK, 0)
+        eng.run_bulk(len(ids) - 9, 0, eng.num_layers)
+        eng.embed_rows(ids[-9:], BUF_STEP, 0)
+        for _ in range(3):          # repeated launches exercise the self-resetting tickets
+            eng.embed_rows(ids[-9:], BUF_STEP, 0)
+            eng.run_layers(BUF_STEP, 0, 9, len(ids) - 9, 0, eng.num_layers)
+        outs.append((eng.read_rows(BUF_BULK, 0, len(ids) - 9).clone(), eng.read_rows(BUF_STEP, 0, 9).clone()))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    eng.close()

@@ -164,3 +164,19 @@ def test_sampling_path_runs(gpu_device):
     res = spec.generate_token_ids(model, rec["prompt"], rec["eos_token_ids"], cfg)
     assert 0 < len(res.predicted_tokens) <= 12
     assert 0.0 <= res.acceptance_rate <= 1.0
+
+
+def test_pipeline_decoder_single_rank_equals_fused_path(gpu_device):
+    """layerskip_amd/pipeline.py drives HipEngine through its building-block API; with one rank (no
+    communication) it must reproduce the fused lsk_spec_step path token for token."""
+    from layerskip_amd.engine import get_engine
+    from layerskip_amd.pipeline import PipelineSpeculativeDecoder, plan_partition
+    rec = load_golden("tiny_gqa_s0")
+    model = _model(rec, gpu_device)
+    spec, _ = _strategies()
+    fast = spec.generate_token_ids(model, rec["prompt"], rec["eos_token_ids"], _config(rec, "self_speculative"))
+    eng = get_engine(model)
+    dec = PipelineSpeculativeDecoder(eng, 0, 1, plan_partition(eng.num_layers, rec["exit_layer"], 1), rec["exit_layer"])
+    res = dec.generate(rec["prompt"], rec["eos_token_ids"], rec["max_steps"], rec["num_speculations"])
+    assert res.predicted_tokens == fast.predicted_tokens
+    assert res.acceptance_rate == pytest.approx(fast.acceptance_rate, abs=1e-12)
