@@ -47,6 +47,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-new-tokens", type=int, default=48)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--gpu-reference", action="store_true",
+                    help="also time the reference's own path on THIS GPU (torch-ROCm eager ops, the restatement in "
+                         "oracle/ with its tensors on the device) -- the 'same-GPU reference' of BASELINE.md section 3")
+    ap.add_argument("--gpu-reference-tokens", type=int, default=128)
     ap.add_argument("--cpu-prompt-len", type=int, default=64)
     return ap.parse_args()
 
@@ -154,10 +158,11 @@ def main():
         engine.set_profile(True)
         traced = one(0)
         torch.cuda.synchronize()
-        ms, launches = engine.get_profile()
+        ms, launches, empty_ms = engine.get_profile()
         engine.set_profile(False)
         back_to_back_ms = engine.time_gateup(0, 1, 64)
-        avg_ms = ms / max(1, launches)
+        bracket_ms = ms / max(1, launches)
+        avg_ms = max(1e-6, bracket_ms - empty_ms)     # HIP-event bracket minus the cost of an empty bracket
         achieved = pb["gate_up"] / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_gateup.json")
@@ -169,6 +174,7 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_launch": pb["gate_up"], "avg_launch_ms": round(avg_ms, 5), "launches_timed": launches,
+            "event_bracket_ms": round(bracket_ms, 5), "empty_bracket_ms": round(empty_ms, 5),
             "back_to_back_launch_ms": round(back_to_back_ms, 5),
         }
         # ---- whole-path decode-bandwidth roofline from the run's own (T_d, n, ctx) ----
@@ -188,6 +194,8 @@ def main():
                                     "frac_of_floor": round((value / world) / (produced / floor_s), 4)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg, model, E, S, strategy, eos)
+        if args.gpu_reference and spec:
+            out["gpu_reference_port"] = gpu_reference(args, cfg, model, E, S, eos, value / world)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -254,6 +262,26 @@ def _trace_steps(strategy, model, prompt, eos, gen):
     finally:
         del strategy.single_step_speculation
     return steps
+
+
+def gpu_reference(args, cfg, model, E, S, eos, engine_tps):
+    """The reference algorithm as the reference runs it on a GPU: HF-style torch eager ops (torch-ROCm),
+    legacy KV cache by torch.cat, S+2 host syncs per step -- same weights, same prompt shape."""
+    from oracle import llama_oracle as lo
+    om = lo.OracleModel.from_hf(model, device=str(model.model.embed_tokens.weight.device))
+    prompt = synthetic.make_prompt(cfg.vocab_size, args.prompt_len, 0)
+    n_new = args.gpu_reference_tokens
+    with torch.inference_mode():
+        lo.self_speculative_generate(om, prompt[:32], eos, 8, E, S)          # warm-up (lazy init, kernels)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        tr = lo.self_speculative_generate(om, prompt, eos, n_new, E, S)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    tps = len(tr.predicted_tokens) / dt
+    return {"value": round(tps, 2), "unit": "tokens/s", "kind": "port (torch-ROCm eager, oracle/llama_oracle.py on cuda)",
+            "sample": f"{args.prompt_len}-token prompt, {len(tr.predicted_tokens)} new tokens, {dt:.2f} s",
+            "acceptance_rate": round(tr.acceptance_rate, 4), "engine_speedup": round(engine_tps / tps, 2)}
 
 
 def cpu_baseline(args, cfg, model, E, S, strategy, eos):

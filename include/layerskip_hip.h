@@ -186,9 +186,11 @@ int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t iters, floa
                     void* stream);
 
 /* Bracket every gate/up launch of the decode path with HIP events on the launch stream (enable=1),
- * then read the summed duration and launch count (this also clears the recording). */
+ * then read the summed duration and launch count (this also clears the recording).  `empty_bracket_ms`
+ * (optional) receives the cost of an empty event bracket on `stream`, to be subtracted per launch. */
 int lsk_engine_set_profile(lsk_engine* e, int32_t enable);
-int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches);
+int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches, float* empty_bracket_ms,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -895,8 +895,10 @@ extern "C" int lsk_engine_set_profile(lsk_engine* e, int32_t enable) {
     return 0;
 }
 
-// Sum of the durations of every gate/up launch bracketed since lsk_engine_set_profile(e, 1).
-extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches) {
+// Sum of the durations of every gate/up launch bracketed since lsk_engine_set_profile(e, 1), and the cost of
+// an EMPTY event bracket on the same stream (two back-to-back hipEventRecord with no kernel between,
+// averaged over 64 pairs): a bracket's elapsed time = kernel duration + that overhead.
+extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches, float* empty_bracket_ms, void* stream) {
     if (!e || !total_ms || !launches) return lsk_fail("null pointer");
     float total = 0.f;
     int n = 0;
@@ -910,5 +912,26 @@ extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* l
     *total_ms = total;
     *launches = n;
     e->ev_used = 0;
+    if (empty_bracket_ms) {
+        hipStream_t st = (hipStream_t)stream;
+        const bool was = e->profile;
+        e->profile = true;
+        // a tiny kernel in front of every bracket so that the start event waits on real work, as in situ
+        for (int i = 0; i < 64; ++i) {
+            hipLaunchKernelGGL(lsk_set_state_kernel, dim3(1), dim3(1), 0, st, e->state, 0, 1);
+            LSK_TRY(profile_event(e, st));
+            LSK_TRY(profile_event(e, st));
+        }
+        float sum = 0.f;
+        for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+            float ms = 0.f;
+            HIP_OK(hipEventSynchronize(e->ev_pool[i + 1]));
+            HIP_OK(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
+            sum += ms;
+        }
+        *empty_bracket_ms = sum / 64.f;
+        e->ev_used = 0;
+        e->profile = was;
+    }
     return 0;
 }

@@ -60,18 +60,21 @@ class OracleModel:
     eps: float
     attn_impl: str = "sdpa"  # what LlamaForCausalLM(config) selects by default in TF5
     dtype: torch.dtype = torch.float32
+    device: torch.device = torch.device("cpu")   # "cuda" = the reference's torch-ROCm eager path (baseline only)
 
     @property
     def num_layers(self) -> int:
         return len(self.layers)
 
     @classmethod
-    def from_hf(cls, model, dtype: Optional[torch.dtype] = None, attn_impl: Optional[str] = None) -> "OracleModel":
+    def from_hf(cls, model, dtype: Optional[torch.dtype] = None, attn_impl: Optional[str] = None,
+                device: str = "cpu") -> "OracleModel":
         """Borrow (or convert) the weights of a ``transformers.LlamaForCausalLM``."""
         cfg = model.config
+        dev = torch.device(device)
 
         def get(t):
-            t = t.detach().to("cpu")
+            t = t.detach().to(dev)
             return t if dtype is None else t.to(dtype)
 
         layers = []
@@ -88,12 +91,12 @@ class OracleModel:
         return cls(
             embed=embed, layers=layers, final_norm=get(model.model.norm.weight),
             lm_head=get(model.lm_head.weight),
-            inv_freq=rot.inv_freq.detach().to("cpu", torch.float32).clone(),
+            inv_freq=rot.inv_freq.detach().to(dev, torch.float32).clone(),
             attention_scaling=float(rot.attention_scaling),
             n_heads=cfg.num_attention_heads, n_kv_heads=cfg.num_key_value_heads, head_dim=head_dim,
             eps=float(cfg.rms_norm_eps),
             attn_impl=attn_impl or getattr(cfg, "_attn_implementation", "sdpa") or "sdpa",
-            dtype=embed.dtype)
+            dtype=embed.dtype, device=dev)
 
 
 # --------------------------------------------------------------------------------------
@@ -193,25 +196,25 @@ def head(om: OracleModel, h):
 # --------------------------------------------------------------------------------------
 # masks (LMU:21-73)
 # --------------------------------------------------------------------------------------
-def make_causal_mask(tgt_len: int, dtype: torch.dtype, past: int) -> torch.Tensor:
+def make_causal_mask(tgt_len: int, dtype: torch.dtype, past: int, device="cpu") -> torch.Tensor:
     """LMU:45-59."""
-    mask = torch.full((tgt_len, tgt_len), torch.finfo(dtype).min)
-    cond = torch.arange(tgt_len)
+    mask = torch.full((tgt_len, tgt_len), torch.finfo(dtype).min, device=device)
+    cond = torch.arange(tgt_len, device=device)
     mask.masked_fill_(cond < (cond + 1).view(tgt_len, 1), 0)
     mask = mask.to(dtype)
     if past > 0:
-        mask = torch.cat([torch.zeros(tgt_len, past, dtype=dtype), mask], dim=-1)
+        mask = torch.cat([torch.zeros(tgt_len, past, dtype=dtype, device=device), mask], dim=-1)
     return mask[None, None, :, :]
 
 
-def decoder_mask(tgt_len: int, src_len: int, dtype: torch.dtype, past: int) -> torch.Tensor:
+def decoder_mask(tgt_len: int, src_len: int, dtype: torch.dtype, past: int, device="cpu") -> torch.Tensor:
     """LMU:21-42 with an all-ones boolean attention_mask of width ``src_len`` (LMU:62-73)."""
-    ones = torch.ones(1, src_len, dtype=torch.bool)
+    ones = torch.ones(1, src_len, dtype=torch.bool, device=device)
     expanded = ones[:, None, None, :].expand(1, 1, tgt_len, src_len).to(dtype)
     inverted = 1.0 - expanded
     expanded_mask = inverted.masked_fill(inverted.to(torch.bool), torch.finfo(dtype).min)
     if tgt_len > 1:
-        return expanded_mask + make_causal_mask(tgt_len, dtype, past)
+        return expanded_mask + make_causal_mask(tgt_len, dtype, past, device)
     return expanded_mask
 
 
@@ -233,9 +236,10 @@ def forward(om: OracleModel, input_ids: torch.Tensor, past) -> ForwardResult:
     """LMU:155-209."""
     _, m = input_ids.shape
     past_len = past[0][0].shape[2] if past else 0
-    pos = torch.arange(past_len, past_len + m, dtype=torch.long).unsqueeze(0)
+    input_ids = input_ids.to(om.device)
+    pos = torch.arange(past_len, past_len + m, dtype=torch.long, device=om.device).unsqueeze(0)
     h = F.embedding(input_ids, om.embed)
-    mask = decoder_mask(m, past_len + m, h.dtype, past_len)
+    mask = decoder_mask(m, past_len + m, h.dtype, past_len, om.device)
     new_past = []
     for idx, lw in enumerate(om.layers):
         h, kv = decoder_layer(om, lw, h, mask, pos, _kv(past, idx))
@@ -247,9 +251,10 @@ def forward_early(om: OracleModel, input_ids, past, exit_layer: int, exit_query_
     """LMU:213-276.  Layers >= exit_layer keep whatever cache they already had."""
     _, m = input_ids.shape
     past_len = past[0][0].shape[2] if past else 0
-    pos = torch.arange(past_len, past_len + m, dtype=torch.long).unsqueeze(0)
+    input_ids = input_ids.to(om.device)
+    pos = torch.arange(past_len, past_len + m, dtype=torch.long, device=om.device).unsqueeze(0)
     h = F.embedding(input_ids, om.embed)
-    mask = decoder_mask(m, past_len + m, h.dtype, past_len)
+    mask = decoder_mask(m, past_len + m, h.dtype, past_len, om.device)
     new_past = list(past) if past else []
     for idx, lw in enumerate(om.layers[:exit_layer]):
         h, kv = decoder_layer(om, lw, h, mask, pos, _kv(past, idx))
@@ -272,10 +277,11 @@ def forward_remainder(om: OracleModel, input_ids, past, exit_layer: int, exit_qu
         draft_past = past[0][0].shape[2]                                   # LMU:296
         full_past = past[-1][0].shape[2] if len(past) == om.num_layers else 0  # LMU:301-305
         seq_with_past = n_gen + draft_past                                 # LMU:307
+    input_ids = input_ids.to(om.device)
     h = F.embedding(input_ids, om.embed)
-    pos = torch.arange(full_past, seq_with_past, dtype=torch.long).unsqueeze(0).view(-1, seq)
-    early_mask = decoder_mask(n_gen, seq_with_past, h.dtype, draft_past)
-    full_mask = decoder_mask(seq, seq_with_past, h.dtype, full_past)
+    pos = torch.arange(full_past, seq_with_past, dtype=torch.long, device=om.device).unsqueeze(0).view(-1, seq)
+    early_mask = decoder_mask(n_gen, seq_with_past, h.dtype, draft_past, om.device)
+    full_mask = decoder_mask(seq, seq_with_past, h.dtype, full_past, om.device)
     new_past = list(past) if past else []
     full_h = None
     for idx, lw in enumerate(om.layers):
@@ -346,7 +352,8 @@ def single_step_speculation(om, input_ids, input_ids_list, output_ids, num_specu
         draft_input = torch.tensor([[tok]])
         if tok in eos_token_ids:
             break
-    draft_t = torch.tensor(drafts, dtype=input_ids.dtype).unsqueeze(0)
+    input_ids = input_ids.to(om.device)
+    draft_t = torch.tensor(drafts, dtype=input_ids.dtype, device=om.device).unsqueeze(0)
     if len(drafts) == 0:
         draft_t = draft_t.reshape(1, 0)
     prefill = torch.cat([input_ids, draft_t], dim=-1)
