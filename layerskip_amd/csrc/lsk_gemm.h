@@ -187,6 +187,9 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, ring[s]), acc, 0, 0, 0);
             const unsigned off = (s < nxt.nvalid) ? nxt.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
             ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
+            // (hipcc sinks these refills into bursts behind later MFMAs, so the ring runs ~8-16 deep; pinning
+            //  "consume s -> refill s" with sched_barrier(0) gives the textbook vmcnt(15) stream but measured
+            //  0..-4 % on every shape -- the HBM pipe is already full at ~8 KiB per wave in flight)
         }
         float* sl = slab + ((u & 1) * LSK_WAVES + w) * 256;
         *(f32x4*)(sl + lane * 4) = acc;

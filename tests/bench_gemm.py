@@ -39,12 +39,15 @@ def run(k, n, m, wgs, with_norm, nbuf=6, iters=60):
 
 shapes = {"qkv": (4096, 12288, True), "o": (4096, 4096, False), "gateup": (4096, 22016, True), "down": (11008, 4096, False),
           "head": (4096, 32000, True)}
+import os
+WGS_LIST = [int(x) for x in os.environ.get('WGS', '128,192,256,384,512,768,1024').split(',')]
+MS = [int(x) for x in os.environ.get('MS', '1,7').split(',')]
 which = sys.argv[1:] or list(shapes)
 for name in which:
     k, n, norm = shapes[name]
-    for m in (1, 7):
+    for m in MS:
         row = []
-        for wgs in (128, 192, 256, 384, 512, 768, 1024):
+        for wgs in (WGS_LIST):
             us, gbs = run(k, n, m, wgs, norm)
             row.append(f"{wgs}:{us:6.1f}us/{gbs:5.0f}")
         print(f"{name:7s} M={m}  " + "  ".join(row), flush=True)
