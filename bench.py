@@ -100,8 +100,12 @@ def main():
                                   device=dev, gen_device=dev)
     torch.cuda.synchronize()
     build_s = time.time() - t0
+    big = sum(p.numel() for p in model.parameters()) * 2 > 100e9      # > 100 GB of bf16: keep one copy only
     engine = get_engine(model, max_ctx=args.prompt_len + args.max_steps + S + 16, max_prompt=args.prompt_len,
-                        target_wgs=args.target_wgs)
+                        target_wgs=args.target_wgs, release_weights=big)
+    if big:
+        args.no_cpu_baseline = True
+        torch.cuda.empty_cache()
     spec = args.strategy == "self_speculative"
     strategy = HipSelfSpeculativeGenerationStrategy() if spec else HipAutoRegressiveGenerationStrategy()
     gen = GenerationConfig(max_steps=args.max_steps, exit_layer=E if spec else -1, num_speculations=S if spec else -1,

@@ -50,7 +50,7 @@ class HipEngine:
     """One engine per (model, device).  Not re-entrant; one caller thread (like the reference)."""
 
     def __init__(self, model, max_ctx: int = 2048, max_prompt: int = 1024, page_size: int = 128,
-                 target_wgs: int = 0, layer_range: Optional[Sequence[int]] = None):
+                 target_wgs: int = 0, layer_range: Optional[Sequence[int]] = None, release_weights: bool = False):
         self.lib = _lib.load()
         cfg = model.config
         weight = model.model.embed_tokens.weight
@@ -72,6 +72,9 @@ class HipEngine:
         self.page_size = page_size
         self.target_wgs = target_wgs
         self.layer_range = tuple(layer_range) if layer_range is not None else (0, self.num_layers)
+        # release_weights: after a projection is packed its HF original is dropped (the model object then
+        # only serves this engine) -- what lets a 70B checkpoint (140 GB bf16) live on ONE 288 GB MI355X
+        self.release_weights = release_weights
         self._handle = ctypes.c_void_p(None)
         self._packed = []           # per-layer packed buffers (kept alive); None outside layer_range
         self._globals = {}
@@ -122,9 +125,19 @@ class HipEngine:
             n1 = layer.input_layernorm.weight.detach().contiguous()
             n2 = layer.post_attention_layernorm.weight.detach().contiguous()
             self._packed.append((wqkv, wo, wgu, wdown, n1, n2))
+            if self.release_weights:
+                torch.cuda.synchronize(self.device)
+                for lin in (a.q_proj, a.k_proj, a.v_proj, a.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+                    lin.weight = torch.nn.Parameter(torch.empty(0, dtype=torch.bfloat16, device=self.device),
+                                                    requires_grad=False)
         head = self._packed_buffer(self.vocab, H)
         self._pack_into(head, m.lm_head.weight, 0, 1, 0)
         self._globals["lm_head"] = head
+        tied = m.lm_head.weight.data_ptr() == m.model.embed_tokens.weight.data_ptr()
+        if self.release_weights and not tied:
+            torch.cuda.synchronize(self.device)
+            m.lm_head.weight = torch.nn.Parameter(torch.empty(0, dtype=torch.bfloat16, device=self.device),
+                                                  requires_grad=False)
         self._globals["embed"] = m.model.embed_tokens.weight.detach().contiguous()
         self._globals["final_norm"] = m.model.norm.weight.detach().contiguous()
         torch.cuda.synchronize(self.device)

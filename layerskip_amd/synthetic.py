@@ -62,6 +62,11 @@ SHAPES: Dict[str, dict] = {
                                        high_freq_factor=4.0,
                                        original_max_position_embeddings=8192),
                      max_position_embeddings=131072, exit_layer=2, num_speculations=4),
+    # The exact llama2-7B projection / vocabulary shapes (K = 4096 and 11008, V = 32000) on 4 layers.
+    "slice-7B": dict(num_hidden_layers=4, hidden_size=4096, intermediate_size=11008,
+                     num_attention_heads=32, num_key_value_heads=32, head_dim=128,
+                     vocab_size=32000, rope_theta=10000.0, max_position_embeddings=4096,
+                     exit_layer=2, num_speculations=6),
     # Wide enough that K > 4096 (two K-chunks in every projection) like 70B / 13B.
     "small-wide": dict(num_hidden_layers=4, hidden_size=5120, intermediate_size=6144,
                        num_attention_heads=40, num_key_value_heads=8, head_dim=128,

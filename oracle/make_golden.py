@@ -43,9 +43,11 @@ CASES = {
                                              num_speculations=12),
     "tiny_d64_s0": synthetic.SyntheticCase("tiny-d64", seed=0, prompt_len=19, prompt_seed=4, max_steps=32),
     "small_wide_s0": synthetic.SyntheticCase("small-wide", seed=0, prompt_len=20, prompt_seed=5, max_steps=12),
+    "slice7b_s0": synthetic.SyntheticCase("slice-7B", seed=0, prompt_len=40, prompt_seed=6, max_steps=20,
+                                          late_damping=0.05),
 }
-# EOS cases are derived: the eos id is the k-th token of the base case's bf16 output.
-EOS_CASES = {"tiny_mha_s0_eos": ("tiny_mha_s0", 17), "tiny_gqa_s0_eos": ("tiny_gqa_s0", 9)}
+# EOS cases are derived: the eos id is the first token at index >= k of the base case's fp32 output that has not occurred before.
+EOS_CASES = {"tiny_mha_s0_eos": ("tiny_mha_s0", 3), "tiny_gqa_s0_eos": ("tiny_gqa_s0", 5), "tiny_mha_s1_eos": ("tiny_mha_s1", 10)}
 
 
 def run_reference(ref, model, prompt, eos, case, strategy):
@@ -147,7 +149,9 @@ def main():
             continue
         if base not in records:
             records[base] = build_case(ref, base, CASES[base])
-        eos_id = records[base]["bf16"]["spec_tokens"][k]
+        toks = records[base]["fp32"]["spec_tokens"]
+        k = next((i for i in range(k, len(toks)) if toks[i] not in toks[:i]), k)   # first occurrence => non-trivial cut
+        eos_id = toks[k]
         records[name] = build_case(ref, name, CASES[base], eos=[eos_id])
     bad = 0
     for name, rec in records.items():
