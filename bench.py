@@ -80,12 +80,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the engine)"
+    # LSK_BENCH_SAME_GPU=1 + LSK_BENCH_BACKEND=gloo: smoke-test the multi-process path on a 1-GPU box
+    backend = os.environ.get("LSK_BENCH_BACKEND", "nccl")
+    if os.environ.get("LSK_BENCH_SAME_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from layerskip_amd.engine import get_engine
     from layerskip_amd.hip_strategies import HipAutoRegressiveGenerationStrategy, HipSelfSpeculativeGenerationStrategy
@@ -135,7 +143,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed, float(tokens)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(tokens)], dtype=torch.float64, device=red_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -196,7 +204,7 @@ def main():
             out["path_roofline"] = {"algorithmic_bytes_per_generation": total_b,
                                     "floor_tokens_per_s_at_8TBs": round(produced / floor_s, 1),
                                     "frac_of_floor": round((value / world) / (produced / floor_s), 4)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, cfg, model, E, S, strategy, eos)
         if args.gpu_reference and spec:
             out["gpu_reference_port"] = gpu_reference(args, cfg, model, E, S, eos, value / world)
@@ -217,7 +225,8 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev):
                                   device=dev, gen_device=dev, layer_range=part[rank])
     engine = HipEngine(model, max_ctx=args.prompt_len + args.max_steps + S + 16, max_prompt=args.prompt_len,
                        target_wgs=args.target_wgs, layer_range=part[rank])
-    dec = PipelineSpeculativeDecoder(engine, rank, world, part, E)
+    comm_dev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    dec = PipelineSpeculativeDecoder(engine, rank, world, part, E, comm_device=comm_dev)
     eos = [cfg.vocab_size]
 
     def one(i):
@@ -232,7 +241,8 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev):
     results = [one(i) for i in range(args.steps)]
     dist.barrier()
     torch.cuda.synchronize()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                     device=dev if dist.get_backend() == "nccl" else torch.device("cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         tokens = sum(len(r.predicted_tokens) for r in results)

@@ -15,8 +15,10 @@
 //           before the second GEMM), transposed C->A layout through 1 KiB of LDS per wave, O = P V.
 //           The 4 waves are merged in a fixed order into ONE (max, sum, acc[d]) partial per
 //           (row, head, page).
-//   phase 2 (lsk_attn_combine_kernel): merges the page partials of a (row, head) in page order, writes
-//           the bf16 attention output.
+//   phase 2: the page partials of a (row, head) are merged in page order into the bf16 attention output
+//           -- by the LAST page-workgroup of the head to arrive, inside the same launch (write-through
+//           partial stores + one relaxed agent-scope ticket, sc1 loads in the reducer; default), or by
+//           lsk_attn_combine_kernel as a second launch (LSK_OPT_FUSED_ATTN = 0; bit-identical).
 // Every row of the MFMA tiles is computed independently and the key partition depends only on the
 // absolute key index, so a row's result never depends on M or on the other rows of the pass.
 // Replaces: LlamaAttention's repeat_kv + eager/SDPA attention (modeling_llama.py:179-213, :264-277).
@@ -27,7 +29,6 @@
 #define LSK_ATTN_THREADS 256
 #define LSK_ATTN_WAVES 4
 #define LSK_ATTN_PAGE 128          // keys per workgroup == KV page size
-#define LSK_ATTN_MAXP 64           // pages the combine kernel prefetches in one go
 
 struct AttnSplitParams {
     const bf16_t* q;        // [M][ldq]

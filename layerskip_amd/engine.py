@@ -308,13 +308,18 @@ class HipEngine:
         }
 
 
-_ENGINE_ATTR = "_layerskip_hip_engine"
+_ENGINES = None
 
 
 def get_engine(model, **kwargs) -> HipEngine:
-    """The engine bound to ``model`` (built lazily on first use, reused across calls)."""
-    eng = getattr(model, _ENGINE_ATTR, None)
+    """The engine bound to ``model`` (built lazily on first use, reused across calls).  Kept in a weak
+    map, not on the module, so ``copy.deepcopy(model)`` and ``state_dict()`` never see it."""
+    global _ENGINES
+    if _ENGINES is None:
+        import weakref
+        _ENGINES = weakref.WeakKeyDictionary()
+    eng = _ENGINES.get(model)
     if eng is None:
         eng = HipEngine(model, **kwargs)
-        object.__setattr__(model, _ENGINE_ATTR, eng)
+        _ENGINES[model] = eng
     return eng

@@ -98,7 +98,7 @@ class PipelineSpeculativeDecoder:
     def _rows_out(self, buffer: int, row_base: int, m: int, dst: int) -> None:
         for r0 in range(0, m, 256):
             k = min(256, m - r0)
-            self._send(self.be.read_rows(buffer, row_base + r0, k), dst)
+            self._send(self.be.read_rows(buffer, row_base + r0, k).to(self.dev), dst)
 
     def _rows_in(self, buffer: int, row_base: int, m: int, src: int) -> None:
         for r0 in range(0, m, 256):

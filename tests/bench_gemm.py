@@ -1,5 +1,6 @@
 """GPU micro-benchmark (not a test): skinny projection kernel bandwidth vs shape / M / grid size."""
 import ctypes
+import os
 import sys
 
 import torch
@@ -12,7 +13,11 @@ dev = torch.device("cuda:0")
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 
 
-def run(k, n, m, wgs, with_norm, nbuf=6, iters=60):
+NBUF = int(os.environ.get('NBUF', '6'))
+
+
+def run(k, n, m, wgs, with_norm, nbuf=None, iters=60):
+    nbuf = nbuf or NBUF
     nbytes = ctypes.c_size_t(0)
     _lib.check(lib.lsk_packed_bytes(n, k, ctypes.byref(nbytes)))
     bufs = [torch.randint(0, 255, (nbytes.value,), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
