@@ -158,6 +158,7 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
 #define LSK_OPT_BIG_THRESHOLD 1   /* rows from which prefill uses the MFMA-tiled kernels (default 48) */
 #define LSK_OPT_TARGET_WGS 2      /* workgroups per skinny projection launch (default 256) */
 #define LSK_OPT_FUSED_ATTN 3      /* 1 (default): page partials combined in-launch by the last arriver; 0: second kernel */
+#define LSK_OPT_FUSED_OPROJ 4     /* 1: attention and o_proj as one role-pipelined launch (rows <= 8); default 0 (measured neutral) */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
 /* Final RMSNorm + lm_head (+ greedy argmax) over rows [row_base, row_base+m)
  * (llama_model_utils.py:204-205, :271-273, :386-387; decode_next_token :120-122).

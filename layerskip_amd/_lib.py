@@ -16,6 +16,7 @@ LSK_ABI_VERSION = 1
 LSK_OPT_BIG_THRESHOLD = 1
 LSK_OPT_TARGET_WGS = 2
 LSK_OPT_FUSED_ATTN = 3
+LSK_OPT_FUSED_OPROJ = 4
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblayerskip_hip.so")
 

@@ -18,6 +18,7 @@
 #include "lsk_common.h"
 #include "lsk_gemm.h"
 #include "lsk_gemm_big.h"
+#include "lsk_fused.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -192,8 +193,11 @@ struct lsk_engine {
     bf16_t* attn = nullptr;       // [16][n_heads*hd]
     bf16_t* act = nullptr;        // [16][I]
     float* attn_part = nullptr;   // [n_heads][n_pages][16][hd + 2] split-KV partials
-    int* attn_cnt = nullptr;      // [n_heads] arrival tickets of the in-launch combine
+    int* attn_cnt = nullptr;      // [n_heads] arrival tickets of the in-launch combine, then heads_done
+    int* heads_done = nullptr;    // monotonic: += n_heads per fused attention+o_proj launch
+    int heads_epoch = 0;          // fused launches since the last reset
     bool fused_attn = true;
+    bool fused_oproj = false;     // measured neutral at 7B (15.7 us fused vs 8.9 + 6.3 + gap): the seam is a latency chain
     bf16_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]
     bf16_t* kv_pool = nullptr;
     size_t kv_layer_elems = 0;    // elements per layer (K and V)
@@ -256,7 +260,7 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.attn = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
     L.act = take(2 * (size_t)LSK_MAX_ROWS * c->intermediate);
     L.attn_part = take(sizeof(float) * (size_t)c->n_heads * L.n_pages * LSK_MAX_ROWS * (c->head_dim + 2));
-    L.attn_cnt = take(sizeof(int) * (size_t)c->n_heads);
+    L.attn_cnt = take(sizeof(int) * (size_t)(c->n_heads + 16));   // tickets per head + heads_done
     L.xn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->hidden);
     L.q_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
     L.attn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
@@ -319,6 +323,10 @@ static int init_kernel_attrs() {
     LSK_TRY((set_gemm_attr<PRO_RMS, EPI_SWIGLU>()));
     LSK_TRY((set_gemm_attr<PRO_RMS, EPI_QKV>()));
     LSK_TRY((set_gemm_attr<PRO_RMS, EPI_HEAD>()));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
     done = true;
     return 0;
 }
@@ -357,6 +365,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->act = (bf16_t*)(e->ws + L.act);
     e->attn_part = (float*)(e->ws + L.attn_part);
     e->attn_cnt = (int*)(e->ws + L.attn_cnt);
+    e->heads_done = e->attn_cnt + cfg->n_heads;
     e->xn_bulk = (bf16_t*)(e->ws + L.xn_bulk);
     e->q_bulk = (bf16_t*)(e->ws + L.q_bulk);
     e->attn_bulk = (bf16_t*)(e->ws + L.attn_bulk);
@@ -373,7 +382,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     hipError_t err = hipMemcpy(e->block_table, table.data(), sizeof(int) * L.n_pages, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
     if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
-    if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * cfg->n_heads);
+    if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * (cfg->n_heads + 16));
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 64, hipHostMallocDefault);
     if (err != hipSuccess) { delete e; return lsk_fail("engine init copy failed: %s", hipGetErrorString(err)); }
     *out = e;
@@ -425,7 +434,8 @@ static int set_kv_len(lsk_engine* e, int kv_len, bool add, hipStream_t st) {
 
 extern "C" int lsk_engine_reset(lsk_engine* e, void* stream) {
     if (!e) return lsk_fail("null engine");
-    HIP_OK(hipMemsetAsync(e->attn_cnt, 0, sizeof(int) * e->cfg.n_heads, (hipStream_t)stream));
+    HIP_OK(hipMemsetAsync(e->attn_cnt, 0, sizeof(int) * (e->cfg.n_heads + 16), (hipStream_t)stream));
+    e->heads_epoch = 0;
     return set_kv_len(e, 0, false, (hipStream_t)stream);
 }
 
@@ -492,19 +502,31 @@ static int check_rows(lsk_engine* e, int buffer, int row_base, int m) {
     return 0;
 }
 
-static int launch_attn(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t* kpool, const bf16_t* vpool, int m, int pos_off, hipStream_t st) {
+static int attn_params(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t* kpool, const bf16_t* vpool, int m, int pos_off,
+                       AttnSplitParams& sp, int& pages) {
     const lsk_config& c = e->cfg;
     const int hd = c.head_dim;
     const int qdim = c.n_heads * hd;
-    AttnSplitParams sp{};
+    sp = AttnSplitParams{};
     sp.q = q; sp.ldq = qdim; sp.kpool = kpool; sp.vpool = vpool; sp.block_table = e->block_table;
     sp.n_kv = c.n_kv_heads; sp.group = c.n_heads / c.n_kv_heads; sp.M = m; sp.kv_len = &e->state->kv_len; sp.pos_off = pos_off;
     sp.scale_log2e = (float)((1.0 / sqrt((double)hd)) * 1.4426950408889634);
     sp.part = e->attn_part; sp.max_pages = e->n_pages;
     sp.counters = e->fused_attn ? e->attn_cnt : nullptr; sp.out = out; sp.ldo = qdim;
     const int last_pos = e->kv_len_host + pos_off + m - 1;
-    const int pages = last_pos / LSK_ATTN_PAGE + 1;
+    pages = last_pos / LSK_ATTN_PAGE + 1;
     if (pages > e->n_pages) return lsk_fail("attention reaches page %d of %d", pages, e->n_pages);
+    sp.n_pages = pages;
+    sp.heads_done = nullptr;
+    return 0;
+}
+
+static int launch_attn(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t* kpool, const bf16_t* vpool, int m, int pos_off, hipStream_t st) {
+    const lsk_config& c = e->cfg;
+    const int hd = c.head_dim;
+    AttnSplitParams sp;
+    int pages = 0;
+    LSK_TRY(attn_params(e, q, out, kpool, vpool, m, pos_off, sp, pages));
     const dim3 grid(c.n_heads, pages), block(LSK_ATTN_THREADS);
     if (hd == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, sp);
     else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, sp);
@@ -512,10 +534,42 @@ static int launch_attn(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t
     if (e->fused_attn) return 0;
     AttnCombineParams cp{};
     cp.part = e->attn_part; cp.max_pages = e->n_pages; cp.M = m; cp.kv_len = &e->state->kv_len; cp.pos_off = pos_off;
-    cp.out = out; cp.ldo = qdim;
+    cp.out = out; cp.ldo = c.n_heads * hd;
     if (hd == 128) hipLaunchKernelGGL((lsk_attn_combine_kernel<128>), dim3(c.n_heads, m), dim3(128), 0, st, cp);
     else hipLaunchKernelGGL((lsk_attn_combine_kernel<64>), dim3(c.n_heads, m), dim3(64), 0, st, cp);
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// attention + o_proj/residual of one layer as ONE role-pipelined launch (lsk_fused.h); m <= 8
+static int launch_attn_oproj(lsk_engine* e, const bf16_t* kpool, const bf16_t* vpool, const LayerWeights& lw, bf16_t* x, int m,
+                             int pos_off, hipStream_t st) {
+    const lsk_config& c = e->cfg;
+    const int hd = c.head_dim;
+    const int qdim = c.n_heads * hd;
+    AttnSplitParams sp;
+    int pages = 0;
+    LSK_TRY(attn_params(e, e->qbuf, e->attn, kpool, vpool, m, pos_off, sp, pages));
+    sp.heads_done = e->heads_done;
+    GemmParams p{};
+    p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
+    p.wp = lw.wo; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
+    p.h = x; p.ldh = c.hidden;
+    p.tiles_per_wg = tiles_per_wg(p.n_tiles, e->target_wgs);
+    const int gemm_grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    const int n_attn = c.n_heads * pages;
+    size_t lds = lsk_gemm_lds_bytes(m, p.K);
+    const size_t attn_lds = hd == 128 ? (size_t)lsk_attn_lds_bytes<128>() : (size_t)lsk_attn_lds_bytes<64>();
+    if (attn_lds > lds) lds = attn_lds;
+    if (lds > kMaxGemmLds) return lsk_fail("fused attention+o_proj LDS %zu exceeds %zu", lds, kMaxGemmLds);
+    const int target = (e->heads_epoch + 1) * c.n_heads;
+    const dim3 grid(n_attn + gemm_grid), block(LSK_THREADS);
+#define LSK_FUSED_CASE(HD, MB) hipLaunchKernelGGL((lsk_attn_oproj_kernel<HD, MB>), grid, block, lds, st, sp, p, n_attn, c.n_heads, (const int*)e->heads_done, target)
+    if (hd == 128) { if (m == 1) LSK_FUSED_CASE(128, 1); else LSK_FUSED_CASE(128, 8); }
+    else { if (m == 1) LSK_FUSED_CASE(64, 1); else LSK_FUSED_CASE(64, 8); }
+#undef LSK_FUSED_CASE
+    HIP_OK(hipGetLastError());
+    e->heads_epoch += 1;
     return 0;
 }
 
@@ -549,8 +603,11 @@ static int run_layers(lsk_engine* e, bf16_t* x, int m, const int* base_ptr, int 
             p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin; p.kv_len = base_ptr; p.pos_off = pos_off;
             LSK_TRY((launch_gemm<PRO_RMS, EPI_QKV>(p, e->target_wgs, st)));
         }
-        LSK_TRY(launch_attn(e, e->qbuf, e->attn, kpool, vpool, m, pos_off, st));
-        {   // o_proj + residual
+        if (e->fused_oproj && e->fused_attn && m <= 8 && e->heads_epoch < (1 << 24)) {
+            LSK_TRY(launch_attn_oproj(e, kpool, vpool, lw, x, m, pos_off, st));
+        } else {
+            LSK_TRY(launch_attn(e, e->qbuf, e->attn, kpool, vpool, m, pos_off, st));
+            // o_proj + residual
             GemmParams p{};
             p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
             p.wp = lw.wo; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
@@ -806,6 +863,7 @@ extern "C" int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t valu
         case LSK_OPT_BIG_THRESHOLD: e->big_threshold = value; return 0;
         case LSK_OPT_TARGET_WGS: e->target_wgs = value > 0 ? value : 256; return 0;
         case LSK_OPT_FUSED_ATTN: e->fused_attn = value != 0; return 0;
+        case LSK_OPT_FUSED_OPROJ: e->fused_oproj = value != 0; return 0;
         default: return lsk_fail("unknown option %d", option);
     }
 }

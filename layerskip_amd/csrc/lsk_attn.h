@@ -47,7 +47,14 @@ struct AttnSplitParams {
     int* counters;          // [n_heads] arrival tickets (self-resetting); nullptr = separate combine kernel
     bf16_t* out;            // [M][ldo] attention output (written by the last-arriving page of a head)
     int ldo;
+    int n_pages;            // page-workgroups per head in this launch
+    int* heads_done;        // optional: bumped once per head after its output rows are published (write-through),
+                            // lets the o_proj role of lsk_attn_oproj_kernel start inside the same launch
 };
+
+#define LSK_ATTN_LDS_PBUF 0
+#define LSK_ATTN_LDS_SM 5120
+template <int HD> constexpr int lsk_attn_lds_bytes() { return 5120 + LSK_ATTN_WAVES * 16 * (HD + 2) * 4 + 16; }
 
 struct AttnCombineParams {
     const float* part;
@@ -60,19 +67,18 @@ struct AttnCombineParams {
 };
 
 template <int HD>
-__global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const AttnSplitParams p) {
+__device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const int head, const int page_l, unsigned char* lds) {
     constexpr int KS = HD / 32;              // k-steps of QK^T
     constexpr int DT = HD / 16;              // output column tiles of PV
     constexpr int PSTRIDE = HD + 2;
     constexpr int PB_STRIDE = 80;            // bytes per P row in LDS: 32 bf16 + 16 B pad
-    __shared__ __attribute__((aligned(16))) unsigned char pbuf[LSK_ATTN_WAVES * 16 * PB_STRIDE];
-    __shared__ float sm[LSK_ATTN_WAVES * 16 * PSTRIDE];
+    unsigned char* pbuf = lds + LSK_ATTN_LDS_PBUF;           // [4 waves][16][80 B]
+    float* sm = (float*)(lds + LSK_ATTN_LDS_SM);              // [4 waves][16][HD + 2]
+    int* s_last_p = (int*)(lds + LSK_ATTN_LDS_SM + LSK_ATTN_WAVES * 16 * PSTRIDE * 4);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int head = blockIdx.x;
-    const int page_l = blockIdx.y;           // logical page
     const int kvh = head / p.group;
     const int c16 = lane & 15;
     const int g = lane >> 4;
@@ -179,29 +185,30 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const 
     // data was written through to memory, so no fence is needed on either side) and combines them in page
     // order -- placement- and arrival-order independent, bit-identical to the two-kernel form.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __shared__ int s_last;
     __syncthreads();
     if (tid == 0) {
         const int ticket = __hip_atomic_fetch_add(p.counters + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (ticket == (int)gridDim.y - 1);
+        *s_last_p = (ticket == p.n_pages - 1);
     }
     __syncthreads();
-    if (!s_last) return;
+    if (!*s_last_p) return;
     const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
-    for (int e = tid; e < M * HD; e += LSK_ATTN_THREADS) {
-        const int r = e / HD;
-        const int d = e - r * HD;
+    const bool publish = p.heads_done != nullptr;
+    for (int e = tid; e < M * (HD / 2); e += LSK_ATTN_THREADS) {
+        const int r = e / (HD / 2);
+        const int d = (e - r * (HD / 2)) * 2;          // two adjacent features per thread: one 32-bit store
         const int n_pages = (base_pos + r) / LSK_ATTN_PAGE + 1;
-        float m = LSK_ATTN_NEG, l = 0.f, a = 0.f;
+        float m = LSK_ATTN_NEG, l = 0.f, a0 = 0.f, a1 = 0.f;
         for (int p0 = 0; p0 < n_pages; p0 += 8) {
-            float mo[8], lo[8], ao[8];
+            float mo[8], lo[8], x0[8], x1[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int pg = min(p0 + i, n_pages - 1);
                 const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
                 mo[i] = __hip_atomic_load(src + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 lo[i] = __hip_atomic_load(src + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ao[i] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x0[i] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x1[i] = __hip_atomic_load(src + d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -210,14 +217,30 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const 
                     const float fa = __builtin_amdgcn_exp2f(m - mn);
                     const float fb = __builtin_amdgcn_exp2f(mo[i] - mn);
                     l = l * fa + lo[i] * fb;
-                    a = a * fa + ao[i] * fb;
+                    a0 = a0 * fa + x0[i] * fb;
+                    a1 = a1 * fa + x1[i] * fb;
                     m = mn;
                 }
             }
         }
-        p.out[(size_t)r * p.ldo + head * HD + d] = f2bf(a / l);
+        const bf16_t o0 = f2bf(a0 / l), o1 = f2bf(a1 / l);
+        const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
+        unsigned* op = (unsigned*)(p.out + (size_t)r * p.ldo + head * HD + d);
+        if (publish) __hip_atomic_store(op, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+        else *op = packed;
     }
-    if (tid == 0) __hip_atomic_store(p.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (publish) __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(p.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (publish) __hip_atomic_fetch_add(p.heads_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const AttnSplitParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[lsk_attn_lds_bytes<HD>()];
+    lsk_attn_body<HD>(p, blockIdx.x, blockIdx.y, lds);
 }
 
 template <int HD>

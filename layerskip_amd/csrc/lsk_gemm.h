@@ -61,14 +61,27 @@ __host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS
 // wave's (in-order) load queue: `lsk_load_chunk` pulls this thread's 16-byte slice of every row of a
 // K-chunk into registers (issued before / under the weight stream), `lsk_store_chunk` applies the
 // RMSNorm (if any) and writes the bf16 rows to LDS later, without touching global memory.
-template <int PRO, int MB>
+template <int PRO, int MB, bool COHERENT = false>
 __device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int steps_c, int tid, bf16x8 (&xr)[MB], bf16x8& nw) {
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
         const int k0 = c * LSK_KC_ELEMS + e0;
         if (PRO == PRO_RMS) nw = *(const bf16x8*)(p.norm_w + k0);
 #pragma unroll
-        for (int i = 0; i < MB; ++i) xr[i] = *(const bf16x8*)(p.x + (size_t)min(i, p.M - 1) * p.ldx + k0);
+        for (int i = 0; i < MB; ++i) {
+            const bf16_t* src = p.x + (size_t)min(i, p.M - 1) * p.ldx + k0;
+            if (COHERENT) {
+                // rows published by another workgroup of the SAME launch with write-through stores: read them
+                // with agent-scope (sc1) loads, which bypass this CU's possibly stale L1 lines
+                unsigned long long lo = __hip_atomic_load((const unsigned long long*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long hi = __hip_atomic_load((const unsigned long long*)src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                u64x2 v = {lo, hi};
+                xr[i] = __builtin_bit_cast(bf16x8, v);
+            } else {
+                xr[i] = *(const bf16x8*)src;
+            }
+        }
     }
 }
 
@@ -95,9 +108,11 @@ __device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned ch
     }
 }
 
-template <int PRO, int EPI, int MB>
-__global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// `wait_flag` != nullptr: the activation rows are produced by other workgroups of the SAME launch (role
+// pipelining, lsk_attn_oproj_kernel): fill the weight ring first, then wait until *wait_flag >= wait_target.
+template <int PRO, int EPI, int MB, bool WAIT>
+__device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int block_id, unsigned char* smem,
+                                              const int* wait_flag, const int wait_target) {
     float* slab = (float*)(smem + LSK_LDS_SLAB);
     float* red = (float*)(smem + LSK_LDS_RED);
     float* inv = (float*)(smem + LSK_LDS_INV);
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ksteps = p.K >> 5;
     const int nchunks = (ksteps + LSK_KC_STEPS - 1) / LSK_KC_STEPS;
-    const int tile0 = blockIdx.x * p.tiles_per_wg;
+    const int tile0 = block_id * p.tiles_per_wg;
     const int ntl = min(p.tiles_per_wg, p.n_tiles - tile0);
     const int units = nchunks * ntl;
     const int xstride = lsk_gemm_xstride(p.K);
@@ -121,13 +136,30 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
     bf16x8 xr[MB];
     bf16x8 nw;
     float ss[MB];
+    u32x4 ring[LSK_SPW];
+    if (WAIT) {
+        // rows not produced yet: start the weight stream, then wait for the producers (bounded spin)
+#pragma unroll
+        for (int s = 0; s < LSK_SPW; ++s) {
+            const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
+            ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
+        }
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_target && spins < (1 << 22)) {
+                __builtin_amdgcn_s_sleep(8);
+                ++spins;
+            }
+        }
+        __syncthreads();
+    }
     if (PRO == PRO_RMS) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) ss[i] = 0.f;
         // RMSNorm statistics need whole rows: walk the K-chunks last-to-first so chunk 0 stays in xr
         for (int c = nchunks - 1; c >= 0; --c) {
             const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
-            lsk_load_chunk<PRO, MB>(p, c, steps_c, tid, xr, nw);
+            lsk_load_chunk<PRO, MB, WAIT>(p, c, steps_c, tid, xr, nw);
             if (tid * 8 < steps_c * 32) {
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
@@ -136,13 +168,14 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
             }
         }
     } else {
-        lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
+        lsk_load_chunk<PRO, MB, WAIT>(p, 0, cur.steps_c, tid, xr, nw);
     }
-    u32x4 ring[LSK_SPW];
+    if (!WAIT) {
 #pragma unroll
-    for (int s = 0; s < LSK_SPW; ++s) {
-        const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
-        ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
+        for (int s = 0; s < LSK_SPW; ++s) {
+            const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
+            ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
+        }
     }
     if (PRO == PRO_RMS) {
 #pragma unroll
@@ -160,7 +193,7 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
         __syncthreads();
     }
     lsk_store_chunk<PRO, MB>(p, xs, xstride, inv, cur.steps_c, tid, xr, nw);
-    if (nchunks > 1) lsk_load_chunk<PRO, MB>(p, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);   // prefetch chunk 1
+    if (nchunks > 1) lsk_load_chunk<PRO, MB, WAIT>(p, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);   // prefetch chunk 1
     __syncthreads();
 
     const int arow = min(lane & 15, M - 1);
@@ -176,7 +209,7 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
             // of this chunk were prefetched into xr one chunk ago, the next chunk's are requested now
             lsk_store_chunk<PRO, MB>(p, xs, xstride, inv, cur.steps_c, tid, xr, nw);
             if (cur.c + 1 < nchunks)
-                lsk_load_chunk<PRO, MB>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
+                lsk_load_chunk<PRO, MB, WAIT>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
             __syncthreads();
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -320,8 +353,14 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams 
                 const int oi = best_i[t * 16 + tid];
                 if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
             }
-            p.part_val[blockIdx.x * 16 + tid] = v;
-            p.part_idx[blockIdx.x * 16 + tid] = idx;
+            p.part_val[block_id * 16 + tid] = v;
+            p.part_idx[block_id * 16 + tid] = idx;
         }
     }
+}
+
+template <int PRO, int EPI, int MB>
+__global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lsk_gemm_body<PRO, EPI, MB, false>(p, blockIdx.x, smem, nullptr, 0);
 }
