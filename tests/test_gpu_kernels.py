@@ -205,3 +205,46 @@ def test_role_pipelined_attention_oproj_is_bit_identical(gpu_device, shape):
     assert torch.isfinite(outs[1].float()).all()
     assert torch.equal(outs[0], outs[1])
     eng.close()
+
+
+def test_paged_kv_block_table_indirection(gpu_device):
+    """The KV pool is paged: a permuted logical->physical block table must give bit-identical results
+    (prefill kernels, decode kernels and attention all go through the table)."""
+    from layerskip_amd import synthetic
+    from layerskip_amd.engine import BUF_BULK, BUF_STEP, HipEngine
+    cfg = synthetic.make_config("tiny-gqa")
+    model = synthetic.build_model(cfg, seed=9, exit_layer=3, late_damping=0.1).to(gpu_device)
+    eng = HipEngine(model, max_ctx=1024, max_prompt=400)
+    n_pages = eng.max_ctx // eng.page_size
+    ids = synthetic.make_prompt(cfg.vocab_size, 300, 12)
+    outs = []
+    for table in (list(range(n_pages)), [(5 * i + 3) % n_pages for i in range(n_pages)]):
+        assert sorted(table) == list(range(n_pages))
+        eng.set_block_table(table)
+        eng.reset()
+        eng.embed_rows(ids[:290], BUF_BULK, 0)
+        eng.run_bulk(290, 0, eng.num_layers)
+        eng.set_kv_len(290)
+        eng.embed_rows(ids[290:297], BUF_STEP, 0)
+        eng.run_layers(BUF_STEP, 0, 7, 0, 0, eng.num_layers)
+        toks = eng.run_head(BUF_STEP, 0, 7)
+        outs.append((eng.read_rows(BUF_STEP, 0, 7).clone(), toks))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    eng.close()
+
+
+def test_engine_grows_context_on_demand(gpu_device):
+    from layerskip_amd import GenerationConfig, synthetic
+    from layerskip_amd.engine import get_engine
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    cfg = synthetic.make_config("tiny-mha")
+    model = synthetic.build_model(cfg, seed=3, exit_layer=2, late_damping=0.1).to(gpu_device)
+    eng = get_engine(model, max_ctx=128, max_prompt=16)
+    strat = HipSelfSpeculativeGenerationStrategy()
+    prompt = synthetic.make_prompt(cfg.vocab_size, 200, 1)            # longer than both initial limits
+    gen = GenerationConfig(max_steps=40, exit_layer=2, num_speculations=4, sample=False)
+    a = strat.generate_token_ids(model, prompt, [cfg.vocab_size], gen)
+    assert eng.max_ctx >= 200 + 40 and eng.max_prompt >= 200
+    b = strat.generate_token_ids(model, prompt, [cfg.vocab_size], gen)
+    assert a.predicted_tokens == b.predicted_tokens and len(a.predicted_tokens) == 40
