@@ -8,7 +8,6 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -479,10 +478,7 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
     const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
     if (lds > kMaxGemmLds) return lsk_fail("gemm LDS %zu exceeds %zu", lds, kMaxGemmLds);
-    static const int force_mb = getenv("LSK_FORCE_MB") ? atoi(getenv("LSK_FORCE_MB")) : 0;   // tuning hook
-    if (force_mb == 8 && p.M <= 8) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 8>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
-    else if (force_mb == 16) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 16>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
-    else if (p.M == 1) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+    if (p.M == 1) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     else if (p.M <= 8) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 8>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 16>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     HIP_OK(hipGetLastError());
