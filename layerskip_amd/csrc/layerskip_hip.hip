@@ -91,25 +91,36 @@ __global__ void lsk_embed_kernel(const bf16_t* __restrict__ embed, const int* __
     for (int i = threadIdx.x; i < hidden / 8; i += blockDim.x) dst[i] = src[i];
 }
 
-// final argmax over the per-workgroup partials of the lm_head kernel (lowest index wins ties)
+// final argmax over the per-workgroup partials of the lm_head kernel (lowest index wins ties); optionally the
+// embedding row of the chosen token is copied straight into the next draft row (saves one launch per draft)
 __global__ void lsk_argmax_finalize_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int n_parts,
-                                           int m, int* __restrict__ tokens_out) {
+                                           int m, int* __restrict__ tokens_out, const bf16_t* __restrict__ embed, int hidden,
+                                           int vocab, bf16_t* __restrict__ embed_dst) {
+    __shared__ int s_tok;
     const int row = blockIdx.x;
     if (row >= m) return;
-    float v = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < n_parts; i += 64) {
-        const float ov = part_val[i * 16 + row];
-        const int oi = part_idx[i * 16 + row];
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    if (threadIdx.x < 64) {
+        float v = -INFINITY;
+        int idx = 0x7fffffff;
+        for (int i = threadIdx.x; i < n_parts; i += 64) {
+            const float ov = part_val[i * 16 + row];
+            const int oi = part_idx[i * 16 + row];
+            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(idx, o, 64);
+            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+        if (threadIdx.x == 0) { tokens_out[row] = idx; s_tok = idx; }
     }
-    if (threadIdx.x == 0) tokens_out[row] = idx;
+    if (embed_dst == nullptr) return;
+    __syncthreads();
+    const int tok = min(max(s_tok, 0), vocab - 1);
+    const bf16x8* src = (const bf16x8*)(embed + (size_t)tok * hidden);
+    bf16x8* dst = (bf16x8*)(embed_dst + (size_t)row * hidden);
+    for (int i = threadIdx.x; i < hidden / 8; i += blockDim.x) dst[i] = src[i];
 }
 
 // Greedy acceptance = longest matching prefix (SSG:186-190) as ONE wavefront: every lane compares one
@@ -631,7 +642,8 @@ static int run_layers(lsk_engine* e, bf16_t* x, int m, const int* base_ptr, int 
 }
 
 // final norm + lm_head + argmax over rows of x; tokens land in tokens_dev[0..m)
-static int run_head(lsk_engine* e, const bf16_t* x, int m, float* logits, int ld_logits, int* tokens_dev, hipStream_t st) {
+static int run_head(lsk_engine* e, const bf16_t* x, int m, float* logits, int ld_logits, int* tokens_dev, hipStream_t st,
+                    bf16_t* embed_dst = nullptr) {
     const lsk_config& c = e->cfg;
     GemmParams p{};
     p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = c.vocab; p.n_tiles = (c.vocab + 15) / 16;
@@ -641,7 +653,8 @@ static int run_head(lsk_engine* e, const bf16_t* x, int m, float* logits, int ld
     int grid = 0;
     LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, e->target_wgs, st, &grid)));
     if (grid > e->max_parts) return lsk_fail("internal: head grid %d > max_parts %d", grid, e->max_parts);
-    hipLaunchKernelGGL(lsk_argmax_finalize_kernel, dim3(m), dim3(64), 0, st, e->part_val, e->part_idx, grid, m, tokens_dev);
+    hipLaunchKernelGGL(lsk_argmax_finalize_kernel, dim3(m), dim3(embed_dst ? 256 : 64), 0, st, e->part_val, e->part_idx, grid, m, tokens_dev,
+                       e->embed, e->cfg.hidden, e->cfg.vocab, embed_dst);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -765,9 +778,9 @@ extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t pr
     // ---- draft loop (SSG:127-148), device resident: row j = input token (j = 0) or draft j ----
     for (int j = 0; j <= S; ++j) {
         bf16_t* xr = e->hrow + (size_t)j * c.hidden;
-        LSK_TRY(embed_rows_dev(e, e->row_tokens + j, 1, xr, st));
+        if (j == 0) LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, xr, st));   // rows j > 0 were embedded by the previous head
         LSK_TRY(run_layers(e, xr, 1, kvp, P - 1 + j, 0, E, st));   // j == S: forward_remainder's early pass (LMU:350-362)
-        if (j < S) LSK_TRY(run_head(e, xr, 1, nullptr, 0, e->row_tokens + j + 1, st));
+        if (j < S) LSK_TRY(run_head(e, xr, 1, nullptr, 0, e->row_tokens + j + 1, st, xr + c.hidden));
     }
     // ---- forward_remainder, late layers (LMU:364-383): exit_query_cache rows + last draft row ----
     if (P > 1) LSK_TRY(run_bulk(e, P - 1, kvp, E, L, st));
