@@ -262,20 +262,8 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev):
 
 def _trace_steps(strategy, model, prompt, eos, gen):
     """(num_drafts, num_matches) of every speculation step of one generation."""
-    steps = []
-    inner = strategy.single_step_speculation
-
-    def spy(**kw):
-        r = inner(**kw)
-        steps.append((r[4], r[3]))
-        return r
-
-    strategy.single_step_speculation = spy
-    try:
-        strategy.generate_token_ids(model, prompt, eos, gen)
-    finally:
-        del strategy.single_step_speculation
-    return steps
+    strategy.generate_token_ids(model, prompt, eos, gen)
+    return list(strategy.last_steps)
 
 
 def gpu_reference(args, cfg, model, E, S, eos, engine_tps):

@@ -131,6 +131,18 @@ int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len,
                   int32_t num_speculations, int32_t exit_layer, const int32_t* eos_token_ids,
                   int32_t n_eos, lsk_step_result* out, void* stream);
 
+/* SelfSpeculativeGenerationStrategy.generate_token_ids (self_speculation_generator.py:32-99), greedy, with
+ * no logits processors / stopping criteria / streamer: the whole generation in ONE call, speculation steps
+ * pipelined on the stream (the next step is enqueued before the host waits for the pending result whenever
+ * the max_steps clamp of SSG:63-66 cannot bind).  out_tokens: host int32[max_steps]; acceptance_rate =
+ * total_matches / total_drafts (SSG:98).  step_drafts / step_matches / n_steps: optional per-step trace
+ * (host int32[max_steps]).  EOS handling as SSG:82-91 (first EOS and everything after it dropped). */
+int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32_t prompt_len,
+                      int32_t num_speculations, int32_t exit_layer, const int32_t* eos_token_ids,
+                      int32_t n_eos, int32_t max_steps, int32_t* out_tokens, int32_t* n_out,
+                      int32_t* total_matches, int32_t* total_drafts, int32_t* step_drafts,
+                      int32_t* step_matches, int32_t* n_steps, void* stream);
+
 /* One iteration of AutoRegressiveGenerationStrategy.generate_token_ids' loop
  * (autoregressive_generator.py:43-75), greedy: `forward` (llama_model_utils.py:155-209) when
  * layer_end == num_layers, `forward_early` (early-exit-only decoding, ARG:44-51) otherwise;

@@ -57,6 +57,9 @@ PROTOTYPES = {
     "lsk_engine_get_kv_len": (c_int32, [c_void_p, POINTER(c_int32)]),
     "lsk_spec_step": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, POINTER(c_int32), c_int32,
                                 POINTER(LskStepResult), c_void_p]),
+    "lsk_spec_generate": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32,
+                                    POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                    POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "lsk_ar_step": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, POINTER(c_int32), c_void_p]),
     "lsk_embed_rows": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
     "lsk_run_layers": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

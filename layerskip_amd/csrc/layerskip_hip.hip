@@ -216,7 +216,8 @@ struct lsk_engine {
     int n_pages = 0;
     int kv_len_host = 0;          // mirror of state->kv_len
     int next_token_host = -1;     // mirror of row_tokens[0] after a step (-1: unknown)
-    int* host_result = nullptr;   // pinned [LSK_RES_INTS]
+    int* host_result = nullptr;   // pinned [2][64]: result blocks of the (up to two) steps in flight
+    hipEvent_t step_done[2] = {nullptr, nullptr};
     int eos_host[LSK_MAX_EOS]; int n_eos_host = -1;
     int target_wgs = 256;
     int big_threshold = 48;       // prompt rows from which the MFMA-tiled prefill kernels take over
@@ -260,7 +261,7 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.row_tokens = take(sizeof(int) * 32);
     L.verified = take(sizeof(int) * 32);
     L.eos = take(sizeof(int) * 16);
-    L.result = take(sizeof(int) * 64);
+    L.result = take(sizeof(int) * 128);
     L.bulk_ids = take(sizeof(int) * (size_t)(c->max_prompt + 16));
     L.part_val = take(sizeof(float) * 16 * (size_t)L.max_parts);
     L.part_idx = take(sizeof(int) * 16 * (size_t)L.max_parts);
@@ -393,7 +394,9 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
     if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
     if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * (cfg->n_heads + 16));
-    if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 64, hipHostMallocDefault);
+    if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 128, hipHostMallocDefault);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[0], hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[1], hipEventDisableTiming);
     if (err != hipSuccess) { delete e; return lsk_fail("engine init copy failed: %s", hipGetErrorString(err)); }
     *out = e;
     return 0;
@@ -403,6 +406,7 @@ extern "C" int lsk_engine_destroy(lsk_engine* e) {
     if (!e) return 0;
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->host_result) (void)hipHostFree(e->host_result);
+    for (int i = 0; i < 2; ++i) if (e->step_done[i]) (void)hipEventDestroy(e->step_done[i]);
     delete e;
     return 0;
 }
@@ -740,26 +744,14 @@ static int check_ids(lsk_engine* e, const int32_t* ids, int n) {
     return 0;
 }
 
-extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t num_speculations, int32_t exit_layer,
-                             const int32_t* eos_token_ids, int32_t n_eos, lsk_step_result* out, void* stream) {
-    LSK_TRY(ready(e));
-    hipStream_t st = (hipStream_t)stream;
-    const lsk_config& c = e->cfg;
-    const int P = prompt_len, S = num_speculations, E = exit_layer, L = c.num_layers;
-    if (!input_ids || !out) return lsk_fail("lsk_spec_step: null pointer");
-    if (P < 1 || P - 1 > c.max_prompt) return lsk_fail("prompt_len %d out of range (max_prompt %d)", P, c.max_prompt);
-    if (S < 0 || S > LSK_MAX_SPEC) return lsk_fail("num_speculations %d out of range 0..%d", S, LSK_MAX_SPEC);
-    if (E < 1 || E > L) return lsk_fail("exit_layer %d out of range 1..%d", E, L);
-    LSK_TRY(layers_bound(e, 0, L));
-    if (n_eos < 0 || n_eos > LSK_MAX_EOS) return lsk_fail("n_eos %d out of range 0..%d", n_eos, LSK_MAX_EOS);
-    if (n_eos > 0 && !eos_token_ids) return lsk_fail("null eos_token_ids");
-    const int C = e->kv_len_host;
-    if (C + P + S > c.max_ctx) return lsk_fail("context overflow: %d + %d + %d > max_ctx %d", C, P, S, c.max_ctx);
-    LSK_TRY(check_ids(e, input_ids, P));
-
-    if (P > 1) HIP_OK(hipMemcpyAsync(e->bulk_ids, input_ids, sizeof(int) * (P - 1), hipMemcpyHostToDevice, st));
-    if (input_ids[P - 1] != e->next_token_host) {   // otherwise the accept kernel already left it in row_tokens[0]
-        HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
+// Upload what a step needs from the host (the prompt rows / a changed input token / a changed eos list).
+static int upload_step_inputs(lsk_engine* e, const int32_t* input_ids, int P, const int32_t* eos_token_ids, int n_eos, hipStream_t st) {
+    if (input_ids) {
+        LSK_TRY(check_ids(e, input_ids, P));
+        if (P > 1) HIP_OK(hipMemcpyAsync(e->bulk_ids, input_ids, sizeof(int) * (P - 1), hipMemcpyHostToDevice, st));
+        if (input_ids[P - 1] != e->next_token_host) {   // otherwise the accept kernel already left it in row_tokens[0]
+            HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
+        }
     }
     if (n_eos != e->n_eos_host || (n_eos > 0 && memcmp(e->eos_host, eos_token_ids, sizeof(int) * n_eos) != 0)) {
         if (n_eos > 0) {
@@ -768,7 +760,17 @@ extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t pr
         }
         e->n_eos_host = n_eos;
     }
+    return 0;
+}
 
+// Enqueue every kernel of ONE speculation step plus the copy of its result block into pinned slot `slot`.
+// Nothing here needs the outcome of the previous step on the host: positions come from the device-side
+// kv_len, the input token of a continuing step sits in row_tokens[0] (left there by the previous accept
+// kernel).  e->kv_len_host only has to be an UPPER bound (bounds checks, attention pages to launch).
+static int enqueue_step(lsk_engine* e, int P, int S, int E, int n_eos, int slot, hipStream_t st) {
+    const lsk_config& c = e->cfg;
+    const int L = c.num_layers;
+    if (e->kv_len_host + P + S > c.max_ctx) return lsk_fail("context overflow: %d + %d + %d > max_ctx %d", e->kv_len_host, P, S, c.max_ctx);
     const int* kvp = &e->state->kv_len;
     // ---- forward_early over the prompt rows that are not the last one (LMU:213-276, rows 0..P-2) ----
     if (P > 1) {
@@ -787,10 +789,35 @@ extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t pr
     LSK_TRY(run_layers(e, e->hrow, S + 1, kvp, P - 1, E, L, st));
     LSK_TRY(run_head(e, e->hrow, S + 1, nullptr, 0, e->verified, st));
     // ---- accept + rollback (SSG:186-221) ----
-    hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, st, e->row_tokens + 1, e->verified, S, e->eos, n_eos, P, e->state, e->result);
+    int* dres = e->result + slot * 64;
+    hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, st, e->row_tokens + 1, e->verified, S, e->eos, n_eos, P, e->state, dres);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(e->host_result, e->result, sizeof(int) * LSK_RES_INTS, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipMemcpyAsync(e->host_result + slot * 64, dres, sizeof(int) * LSK_RES_INTS, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipEventRecord(e->step_done[slot], st));
+    return 0;
+}
+
+static int validate_step_args(lsk_engine* e, int P, int S, int E, const int32_t* eos_token_ids, int n_eos) {
+    const lsk_config& c = e->cfg;
+    if (P < 1 || P - 1 > c.max_prompt) return lsk_fail("prompt_len %d out of range (max_prompt %d)", P, c.max_prompt);
+    if (S < 0 || S > LSK_MAX_SPEC) return lsk_fail("num_speculations %d out of range 0..%d", S, LSK_MAX_SPEC);
+    if (E < 1 || E > c.num_layers) return lsk_fail("exit_layer %d out of range 1..%d", E, c.num_layers);
+    LSK_TRY(layers_bound(e, 0, c.num_layers));
+    if (n_eos < 0 || n_eos > LSK_MAX_EOS) return lsk_fail("n_eos %d out of range 0..%d", n_eos, LSK_MAX_EOS);
+    if (n_eos > 0 && !eos_token_ids) return lsk_fail("null eos_token_ids");
+    return 0;
+}
+
+extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t num_speculations, int32_t exit_layer,
+                             const int32_t* eos_token_ids, int32_t n_eos, lsk_step_result* out, void* stream) {
+    LSK_TRY(ready(e));
+    hipStream_t st = (hipStream_t)stream;
+    const int P = prompt_len, S = num_speculations;
+    if (!input_ids || !out) return lsk_fail("lsk_spec_step: null pointer");
+    LSK_TRY(validate_step_args(e, P, S, exit_layer, eos_token_ids, n_eos));
+    LSK_TRY(upload_step_inputs(e, input_ids, P, eos_token_ids, n_eos, st));
+    LSK_TRY(enqueue_step(e, P, S, exit_layer, n_eos, 0, st));
+    HIP_OK(hipEventSynchronize(e->step_done[0]));
     const int* host_res = e->host_result;
     memset(out, 0, sizeof(*out));
     out->num_matches = host_res[0];
@@ -803,6 +830,83 @@ extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t pr
     for (int i = 0; i <= S; ++i) out->verified_tokens[i] = host_res[LSK_RES_VERIFIED + i];
     e->next_token_host = host_res[2];
     e->kv_len_host = host_res[3];
+    return 0;
+}
+
+// SelfSpeculativeGenerationStrategy.generate_token_ids (self_speculation_generator.py:32-99), greedy, without
+// logits processors / stopping criteria / streamer: the whole generation in one call.  Steps are PIPELINED on
+// the stream: whenever the next step's parameters do not depend on the pending result (the max_steps clamp of
+// SSG:63-66 cannot bind even if every draft is accepted) it is enqueued BEFORE the host waits for that result,
+// so the GPU never idles across a step boundary.  An EOS makes one enqueued step redundant; its effects are
+// confined to KV slots beyond the final length and are discarded.
+extern "C" int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32_t prompt_len, int32_t num_speculations,
+                                 int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, int32_t max_steps,
+                                 int32_t* out_tokens, int32_t* n_out, int32_t* total_matches, int32_t* total_drafts,
+                                 int32_t* step_drafts, int32_t* step_matches, int32_t* n_steps, void* stream) {
+    LSK_TRY(ready(e));
+    hipStream_t st = (hipStream_t)stream;
+    if (!prompt_ids || !out_tokens || !n_out || !total_matches || !total_drafts) return lsk_fail("lsk_spec_generate: null pointer");
+    if (max_steps < 1) return lsk_fail("max_steps %d < 1", max_steps);
+    const int S = num_speculations < 0 ? 0 : num_speculations;
+    LSK_TRY(validate_step_args(e, prompt_len, S, exit_layer, eos_token_ids, n_eos));
+    if (prompt_len + max_steps + S + 1 > e->cfg.max_ctx) return lsk_fail("context overflow: prompt %d + max_steps %d + %d > max_ctx %d", prompt_len, max_steps, S + 1, e->cfg.max_ctx);
+    LSK_TRY(lsk_engine_reset(e, stream));
+    LSK_TRY(upload_step_inputs(e, prompt_ids, prompt_len, eos_token_ids, n_eos, st));
+    int produced = 0, matches = 0, drafts = 0, steps = 0;
+    int kv_true = 0;                         // verified context length after the last COLLECTED step
+    int pend_P = prompt_len, pend_S = S < max_steps - 1 ? S : max_steps - 1, slot = 0;
+    if (pend_S < 0) pend_S = 0;
+    e->kv_len_host = 0;
+    LSK_TRY(enqueue_step(e, pend_P, pend_S, exit_layer, n_eos, slot, st));
+    bool done = false;
+    while (!done) {
+        // the pending step emits between 1 and pend_S + 1 tokens; can the next one be decided already?
+        const int worst = produced + pend_S + 1;
+        const bool early = (max_steps - worst - 1 >= S);
+        int next_slot = slot ^ 1;
+        if (early) {
+            e->kv_len_host = kv_true + pend_P + pend_S;          // upper bound of the context after the pending step
+            LSK_TRY(enqueue_step(e, 1, S, exit_layer, n_eos, next_slot, st));
+        }
+        HIP_OK(hipEventSynchronize(e->step_done[slot]));
+        const int* r = e->host_result + slot * 64;
+        const int n = r[0], td = r[1];
+        kv_true = r[3];
+        matches += n;
+        drafts += td;
+        if (step_drafts) step_drafts[steps] = td;
+        if (step_matches) step_matches[steps] = n;
+        ++steps;
+        const int before = produced;
+        for (int i = 0; i <= n && produced < max_steps; ++i) out_tokens[produced++] = r[LSK_RES_EMIT + i];
+        // SSG:82-91: the first eos id IN LIST ORDER that occurs in the output truncates it at its first position
+        for (int k = 0; k < n_eos && !done; ++k)
+            for (int i = before; i < produced; ++i)
+                if (out_tokens[i] == eos_token_ids[k]) { produced = i; done = true; break; }
+        if (produced >= max_steps) done = true;
+        if (done) {
+            if (early) HIP_OK(hipEventSynchronize(e->step_done[next_slot]));   // drain the redundant step
+            break;
+        }
+        if (!early) {
+            const int s_next = S < max_steps - produced - 1 ? S : max_steps - produced - 1;
+            e->kv_len_host = kv_true;
+            LSK_TRY(enqueue_step(e, 1, s_next < 0 ? 0 : s_next, exit_layer, n_eos, next_slot, st));
+            pend_S = s_next < 0 ? 0 : s_next;
+        } else {
+            pend_S = S;
+        }
+        pend_P = 1;
+        slot = next_slot;
+    }
+    HIP_OK(hipStreamSynchronize(st));
+    // leave the engine consistent with the device: the verified length (a drained redundant step may have moved it)
+    LSK_TRY(set_kv_len(e, kv_true, false, st));
+    e->next_token_host = -1;
+    *n_out = produced;
+    *total_matches = matches;
+    *total_drafts = drafts;
+    if (n_steps) *n_steps = steps;
     return 0;
 }
 

@@ -233,6 +233,22 @@ class HipEngine:
         return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
                           list(res.draft_tokens[:s]), list(res.verified_tokens[: s + 1]))
 
+    def spec_generate(self, prompt_ids: Sequence[int], num_speculations: int, exit_layer: int,
+                      eos_token_ids: Sequence[int], max_steps: int):
+        """Whole greedy generation in one C-ABI call.  Returns (tokens, matches, drafts, [(T_d, n) per step])."""
+        ids = _i32_array(prompt_ids)
+        eos = [t for t in eos_token_ids if 0 <= t < self.vocab][: _lib.LSK_MAX_EOS]
+        eos_arr = _i32_array(eos)
+        out = (ctypes.c_int32 * max_steps)()
+        sd = (ctypes.c_int32 * max_steps)()
+        sm = (ctypes.c_int32 * max_steps)()
+        n_out, tm, td, ns = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        check(self.lib.lsk_spec_generate(self._handle, ids, len(prompt_ids), int(num_speculations), int(exit_layer), eos_arr,
+                                         len(eos), int(max_steps), out, ctypes.byref(n_out), ctypes.byref(tm), ctypes.byref(td),
+                                         sd, sm, ctypes.byref(ns), self._stream))
+        steps = [(sd[i], sm[i]) for i in range(ns.value)]
+        return list(out[: n_out.value]), tm.value, td.value, steps
+
     def ar_step(self, input_ids: Sequence[int], layer_end: Optional[int] = None) -> int:
         ids = _i32_array(input_ids)
         tok = ctypes.c_int32(0)

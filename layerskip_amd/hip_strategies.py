@@ -75,8 +75,12 @@ def _residual_distribution(p_verify: torch.Tensor, p_draft: torch.Tensor, eps: f
 
 
 class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
-    def __init__(self, engine_kwargs: Optional[dict] = None) -> None:
+    def __init__(self, engine_kwargs: Optional[dict] = None, fused_generate: bool = True) -> None:
         self.engine_kwargs = engine_kwargs or {}
+        # fused_generate: greedy generations without processors / criteria / streamer run as ONE C-ABI call
+        # (lsk_spec_generate: the loop of SSG:51-95 with the steps pipelined on the stream)
+        self.fused_generate = fused_generate
+        self.last_steps = []              # [(num_drafts, num_matches)] of the last fused generation
 
     # ------------------------------------------------------------------------------ outer loop
     def generate_token_ids(self, model, input_ids: List[int], eos_token_ids: List[int],
@@ -86,6 +90,14 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         spec = max(0, int(generation_config.num_speculations))
         engine.ensure_capacity(len(input_ids) + generation_config.max_steps + spec + 2, len(input_ids))
         engine.reset()                                            # past_key_values = None
+        if (self.fused_generate and not generation_config.sample and not logits_processors and not stopping_criteria
+                and streamer is None and spec <= _lib.LSK_MAX_SPEC and hasattr(engine, "spec_generate")
+                and "single_step_speculation" not in self.__dict__):
+            if not (1 <= generation_config.exit_layer < engine.num_layers):
+                raise ValueError(f"exit_layer={generation_config.exit_layer} must be in [1, {engine.num_layers})")
+            tokens, matches, drafts, self.last_steps = engine.spec_generate(
+                list(input_ids), spec, generation_config.exit_layer, eos_token_ids, generation_config.max_steps)
+            return GenerationStrategyResult(predicted_tokens=tokens, acceptance_rate=matches / drafts)
         past = None
         input_ids_list = list(input_ids)
         cur = torch.tensor([input_ids_list])
