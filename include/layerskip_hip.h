@@ -150,6 +150,13 @@ int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32_t prompt_l
 int lsk_ar_step(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int32_t layer_end,
                 int32_t* next_token, void* stream);
 
+/* AutoRegressiveGenerationStrategy.generate_token_ids (autoregressive_generator.py:26-80), greedy, without
+ * processors / criteria / streamer, as one call: each argmax is embedded into the next input row on the device,
+ * the host inspects the ids every 8 tokens for EOS (not emitted, ARG:66-67).  out_tokens: host int32[max_steps]. */
+int lsk_ar_generate(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int32_t layer_end,
+                    const int32_t* eos_token_ids, int32_t n_eos, int32_t max_steps, int32_t* out_tokens,
+                    int32_t* n_out, void* stream);
+
 /* ---- building blocks (slow path with logits processors / sampling, and kernel parity tests) -- */
 
 /* h[buffer][row_base + i] = embed_tokens(ids[i])  (llama_model_utils.py:182,242,310).

@@ -61,6 +61,8 @@ PROTOTYPES = {
                                     POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                     POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "lsk_ar_step": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, POINTER(c_int32), c_void_p]),
+    "lsk_ar_generate": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, POINTER(c_int32), c_int32, c_int32,
+                                  POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "lsk_embed_rows": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
     "lsk_run_layers": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "lsk_run_bulk": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -938,6 +938,65 @@ extern "C" int lsk_ar_step(lsk_engine* e, const int32_t* input_ids, int32_t n_id
     return 0;
 }
 
+// AutoRegressiveGenerationStrategy.generate_token_ids (autoregressive_generator.py:26-80), greedy, without
+// processors / criteria / streamer, in one call: the argmax of step t is embedded straight into the input row of
+// step t+1 on the device; the host only looks at the produced ids every AR_BLOCK tokens (EOS check, ARG:66-67),
+// so at most AR_BLOCK-1 redundant forward passes run after an EOS (their KV slots lie beyond the final length).
+#define LSK_AR_BLOCK 8
+extern "C" int lsk_ar_generate(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int32_t layer_end, const int32_t* eos_token_ids,
+                               int32_t n_eos, int32_t max_steps, int32_t* out_tokens, int32_t* n_out, void* stream) {
+    LSK_TRY(ready(e));
+    hipStream_t st = (hipStream_t)stream;
+    const lsk_config& c = e->cfg;
+    if (!input_ids || !out_tokens || !n_out) return lsk_fail("lsk_ar_generate: null pointer");
+    if (n_ids < 1 || n_ids - 1 > c.max_prompt) return lsk_fail("n_ids %d out of range", n_ids);
+    if (layer_end < 1 || layer_end > c.num_layers) return lsk_fail("layer_end %d out of range", layer_end);
+    if (max_steps < 1) return lsk_fail("max_steps %d < 1", max_steps);
+    if (n_eos < 0 || n_eos > LSK_MAX_EOS || (n_eos > 0 && !eos_token_ids)) return lsk_fail("bad eos list");
+    LSK_TRY(layers_bound(e, 0, layer_end));
+    if (n_ids + max_steps + LSK_AR_BLOCK > c.max_ctx) return lsk_fail("context overflow: %d + %d > max_ctx %d", n_ids, max_steps + LSK_AR_BLOCK, c.max_ctx);
+    LSK_TRY(check_ids(e, input_ids, n_ids));
+    LSK_TRY(lsk_engine_reset(e, stream));
+    const int P = n_ids;
+    if (P > 1) HIP_OK(hipMemcpyAsync(e->bulk_ids, input_ids, sizeof(int) * (P - 1), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
+    e->next_token_host = -1;
+    const int* kvp = &e->state->kv_len;
+    if (P > 1) {
+        LSK_TRY(embed_rows_dev(e, e->bulk_ids, P - 1, e->hbulk, st));
+        LSK_TRY(run_bulk(e, P - 1, kvp, 0, layer_end, st));
+    }
+    LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, e->hrow, st));
+    int produced = 0, fed = P;          // tokens accepted so far; tokens whose KV the next pass appends after
+    bool done = false;
+    int first = 1;
+    while (!done) {
+        const int blk = (max_steps - produced) < LSK_AR_BLOCK ? (max_steps - produced) : LSK_AR_BLOCK;
+        for (int i = 0; i < blk; ++i) {
+            // the row at hrow[0] is the embedding of the current input token; it sits at position kv_len + (P-1 | 0)
+            LSK_TRY(run_layers(e, e->hrow, 1, kvp, first ? P - 1 : 0, 0, layer_end, st));
+            LSK_TRY(run_head(e, e->hrow, 1, nullptr, 0, e->verified + i, st, e->hrow));   // next token -> hrow[0]
+            LSK_TRY(set_kv_len(e, first ? P : 1, true, st));
+            first = 0;
+        }
+        HIP_OK(hipMemcpyAsync(e->host_result, e->verified, sizeof(int) * blk, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        for (int i = 0; i < blk && !done; ++i) {
+            const int tok = e->host_result[i];
+            for (int k = 0; k < n_eos; ++k)
+                if (tok == eos_token_ids[k]) done = true;          // EOS is not emitted (ARG:66-67)
+            if (!done) { out_tokens[produced++] = tok; ++fed; }
+        }
+        if (produced >= max_steps) done = true;
+    }
+    // the verified context = prompt + emitted tokens minus the last one (its KV was never needed / is beyond the cut)
+    LSK_TRY(set_kv_len(e, P + (produced > 0 ? produced - 1 : 0), false, st));
+    HIP_OK(hipStreamSynchronize(st));
+    (void)fed;
+    *n_out = produced;
+    return 0;
+}
+
 // ---- building blocks -------------------------------------------------------------------------------
 extern "C" int lsk_embed_rows(lsk_engine* e, const int32_t* ids, int32_t n, int32_t buffer, int32_t row_base, void* stream) {
     LSK_TRY(ready(e));

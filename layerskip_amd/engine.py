@@ -249,6 +249,18 @@ class HipEngine:
         steps = [(sd[i], sm[i]) for i in range(ns.value)]
         return list(out[: n_out.value]), tm.value, td.value, steps
 
+    def ar_generate(self, input_ids: Sequence[int], layer_end: Optional[int], eos_token_ids: Sequence[int],
+                    max_steps: int) -> List[int]:
+        """Whole greedy autoregressive generation in one C-ABI call."""
+        ids = _i32_array(input_ids)
+        eos = [t for t in eos_token_ids if 0 <= t < self.vocab][: _lib.LSK_MAX_EOS]
+        eos_arr = _i32_array(eos)
+        out = (ctypes.c_int32 * max_steps)()
+        n_out = ctypes.c_int32(0)
+        check(self.lib.lsk_ar_generate(self._handle, ids, len(input_ids), int(layer_end or self.num_layers), eos_arr,
+                                       len(eos), int(max_steps), out, ctypes.byref(n_out), self._stream))
+        return list(out[: n_out.value])
+
     def ar_step(self, input_ids: Sequence[int], layer_end: Optional[int] = None) -> int:
         ids = _i32_array(input_ids)
         tok = ctypes.c_int32(0)

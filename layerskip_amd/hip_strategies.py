@@ -249,18 +249,23 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
 
 
 class HipAutoRegressiveGenerationStrategy(GenerationStrategy):
-    def __init__(self, engine_kwargs: Optional[dict] = None) -> None:
+    def __init__(self, engine_kwargs: Optional[dict] = None, fused_generate: bool = True) -> None:
         self.engine_kwargs = engine_kwargs or {}
+        self.fused_generate = fused_generate
 
     def generate_token_ids(self, model, input_ids: List[int], eos_token_ids: List[int],
                            generation_config: GenerationConfig, logits_processors=None, stopping_criteria=None,
                            streamer=None) -> GenerationStrategyResult:
         engine = get_engine(model, **self.engine_kwargs)
-        engine.ensure_capacity(len(input_ids) + generation_config.max_steps + 2, len(input_ids))
+        engine.ensure_capacity(len(input_ids) + generation_config.max_steps + 10, len(input_ids))
         engine.reset()
         layer_end = generation_config.exit_layer if generation_config.exit_layer > 0 else engine.num_layers
         if layer_end > engine.num_layers:
             raise ValueError(f"exit_layer={layer_end} > num_layers={engine.num_layers}")
+        if (self.fused_generate and not generation_config.sample and not logits_processors and not stopping_criteria
+                and streamer is None and hasattr(engine, "ar_generate")):
+            tokens = engine.ar_generate([int(t) for t in input_ids], layer_end, eos_token_ids, generation_config.max_steps)
+            return GenerationStrategyResult(predicted_tokens=tokens, acceptance_rate=None)
         cur = [int(t) for t in input_ids]
         cur_t = torch.tensor([cur])
         output_ids: List[int] = []

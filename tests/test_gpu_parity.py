@@ -307,3 +307,26 @@ def test_pipelined_generate_equals_stepwise(gpu_device, name):
     # the engine is left consistent: a further generation gives the same answer
     c = fused.generate_token_ids(model, rec["prompt"], eos, cfg)
     assert c.predicted_tokens == a.predicted_tokens
+
+
+@pytest.mark.parametrize("name", ["tiny_mha_s0", "tiny_gqa_long"])
+def test_fused_autoregressive_generate_equals_stepwise(gpu_device, name):
+    """lsk_ar_generate (device-resident token feedback, EOS checked every 8 tokens) vs one lsk_ar_step per token."""
+    from layerskip_amd.hip_strategies import HipAutoRegressiveGenerationStrategy
+    rec = load_golden(name)
+    model = _model(rec, gpu_device)
+    cfg = _config(rec, "autoregressive")
+    cfg.exit_layer = -1
+    fused = HipAutoRegressiveGenerationStrategy(fused_generate=True)
+    stepwise = HipAutoRegressiveGenerationStrategy(fused_generate=False)
+    free = fused.generate_token_ids(model, rec["prompt"], [model.config.vocab_size], cfg).predicted_tokens
+    assert free == stepwise.generate_token_ids(model, rec["prompt"], [model.config.vocab_size], cfg).predicted_tokens
+    assert len(free) == rec["max_steps"]
+    k = next(i for i in range(3, len(free)) if free[i] not in free[:i])
+    eos = [free[k]]
+    a = fused.generate_token_ids(model, rec["prompt"], eos, cfg).predicted_tokens
+    b = stepwise.generate_token_ids(model, rec["prompt"], eos, cfg).predicted_tokens
+    assert a == b == free[:k]
+    cfg.exit_layer = rec["exit_layer"]            # early-exit-only decoding through the same call
+    assert (fused.generate_token_ids(model, rec["prompt"], eos, cfg).predicted_tokens
+            == stepwise.generate_token_ids(model, rec["prompt"], eos, cfg).predicted_tokens)
