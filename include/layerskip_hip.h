@@ -205,12 +205,11 @@ int lsk_test_accept(const int32_t* draft, const int32_t* verified, int32_t num_d
 int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t iters, float* ms_per_launch,
                     void* stream);
 
-/* Bracket every gate/up launch of the decode path with HIP events on the launch stream (enable=1),
- * then read the summed duration and launch count (this also clears the recording).  `empty_bracket_ms`
- * (optional) receives the cost of an empty event bracket on `stream`, to be subtracted per launch. */
+/* Profiling of the dominant kernel: while enabled, every gate/up launch of the decode path is issued with its
+ * own (start, stop) HIP events bound to the dispatch's begin / end timestamps (hipExtLaunchKernelGGL) on the
+ * launch stream; lsk_engine_get_profile returns the summed duration and the launch count and clears the log. */
 int lsk_engine_set_profile(lsk_engine* e, int32_t enable);
-int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches, float* empty_bracket_ms,
-                           void* stream);
+int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches);
 
 #ifdef __cplusplus
 }

@@ -74,7 +74,7 @@ PROTOTYPES = {
     "lsk_test_accept": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "lsk_time_gateup": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p]),
     "lsk_engine_set_profile": (c_int32, [c_void_p, c_int32]),
-    "lsk_engine_get_profile": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32), POINTER(c_float), c_void_p]),
+    "lsk_engine_get_profile": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32)]),
 }
 
 _LIB = None

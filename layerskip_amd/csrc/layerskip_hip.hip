@@ -4,6 +4,7 @@
 #include "../../include/layerskip_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdarg.h>
@@ -486,14 +487,20 @@ static int tiles_per_wg(int n_units, int target_wgs) {   // units = tiles (or ga
 }
 
 template <int PRO, int EPI>
-static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_out = nullptr) {
+static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_out = nullptr, hipEvent_t ev_start = nullptr,
+                       hipEvent_t ev_stop = nullptr) {
     const int unit = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int n_units = p.n_tiles / unit;
     p.tiles_per_wg = tiles_per_wg(n_units, target_wgs) * unit;
     const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
     if (lds > kMaxGemmLds) return lsk_fail("gemm LDS %zu exceeds %zu", lds, kMaxGemmLds);
-    if (p.M == 1) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+    if (ev_start != nullptr) {
+        // profiling: the events are bound to THIS dispatch's own begin / end timestamps (what rocprofv3 reports)
+        if (p.M == 1) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
+        else if (p.M <= 8) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 8>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
+        else hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 16>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
+    } else if (p.M == 1) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     else if (p.M <= 8) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 8>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 16>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     HIP_OK(hipGetLastError());
@@ -584,13 +591,15 @@ static int launch_attn_oproj(lsk_engine* e, const bf16_t* kpool, const bf16_t* v
     return 0;
 }
 
-static int profile_event(lsk_engine* e, hipStream_t st) {
-    if (e->ev_used == e->ev_pool.size()) {
+// next (start, stop) event pair of the profile pool
+static int profile_pair(lsk_engine* e, hipEvent_t* a, hipEvent_t* b) {
+    while (e->ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t ev;
         HIP_OK(hipEventCreate(&ev));
         e->ev_pool.push_back(ev);
     }
-    HIP_OK(hipEventRecord(e->ev_pool[e->ev_used++], st));
+    *a = e->ev_pool[e->ev_used++];
+    *b = e->ev_pool[e->ev_used++];
     return 0;
 }
 
@@ -630,9 +639,9 @@ static int run_layers(lsk_engine* e, bf16_t* x, int m, const int* base_ptr, int 
             p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
             p.wp = lw.wgu; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
             p.norm_w = lw.norm2; p.eps = c.rms_eps; p.act = e->act; p.ldact = c.intermediate;
-            if (e->profile) LSK_TRY(profile_event(e, st));
-            LSK_TRY((launch_gemm<PRO_RMS, EPI_SWIGLU>(p, e->target_wgs, st)));
-            if (e->profile) LSK_TRY(profile_event(e, st));
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (e->profile) LSK_TRY(profile_pair(e, &ea, &eb));
+            LSK_TRY((launch_gemm<PRO_RMS, EPI_SWIGLU>(p, e->target_wgs, st, nullptr, ea, eb)));
         }
         {   // down_proj + residual
             GemmParams p{};
@@ -1129,10 +1138,10 @@ extern "C" int lsk_engine_set_profile(lsk_engine* e, int32_t enable) {
     return 0;
 }
 
-// Sum of the durations of every gate/up launch bracketed since lsk_engine_set_profile(e, 1), and the cost of
-// an EMPTY event bracket on the same stream (two back-to-back hipEventRecord with no kernel between,
-// averaged over 64 pairs): a bracket's elapsed time = kernel duration + that overhead.
-extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches, float* empty_bracket_ms, void* stream) {
+// Sum of the durations of every gate/up launch since lsk_engine_set_profile(e, 1).  Each launch went through
+// hipExtLaunchKernelGGL with its own (start, stop) events, i.e. the dispatch's begin / end timestamps -- the same
+// quantity rocprofv3 --kernel-trace reports -- so no event-record overhead is included.
+extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches) {
     if (!e || !total_ms || !launches) return lsk_fail("null pointer");
     float total = 0.f;
     int n = 0;
@@ -1146,26 +1155,5 @@ extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* l
     *total_ms = total;
     *launches = n;
     e->ev_used = 0;
-    if (empty_bracket_ms) {
-        hipStream_t st = (hipStream_t)stream;
-        const bool was = e->profile;
-        e->profile = true;
-        // a tiny kernel in front of every bracket so that the start event waits on real work, as in situ
-        for (int i = 0; i < 64; ++i) {
-            hipLaunchKernelGGL(lsk_set_state_kernel, dim3(1), dim3(1), 0, st, e->state, 0, 1);
-            LSK_TRY(profile_event(e, st));
-            LSK_TRY(profile_event(e, st));
-        }
-        float sum = 0.f;
-        for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
-            float ms = 0.f;
-            HIP_OK(hipEventSynchronize(e->ev_pool[i + 1]));
-            HIP_OK(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
-            sum += ms;
-        }
-        *empty_bracket_ms = sum / 64.f;
-        e->ev_used = 0;
-        e->profile = was;
-    }
     return 0;
 }

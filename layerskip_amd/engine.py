@@ -318,10 +318,10 @@ class HipEngine:
         check(self.lib.lsk_engine_set_profile(self._handle, 1 if enable else 0))
 
     def get_profile(self):
-        """(sum of bracket times in ms, launches, cost of an empty event bracket in ms)."""
-        ms, n, empty = ctypes.c_float(0.0), ctypes.c_int32(0), ctypes.c_float(0.0)
-        check(self.lib.lsk_engine_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(empty), self._stream))
-        return ms.value, n.value, empty.value
+        """(sum of the gate/up dispatch durations in ms, number of launches)."""
+        ms, n = ctypes.c_float(0.0), ctypes.c_int32(0)
+        check(self.lib.lsk_engine_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     # bytes one launch of each projection streams from HBM (algorithmic: the packed weights once)
     def projection_bytes(self) -> dict:
