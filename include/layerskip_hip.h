@@ -177,6 +177,7 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
 #define LSK_OPT_BIG_THRESHOLD 1   /* rows from which prefill uses the MFMA-tiled kernels (default 48) */
 #define LSK_OPT_TARGET_WGS 2      /* workgroups per skinny projection launch (default 256) */
 #define LSK_OPT_FUSED_ATTN 3      /* 1 (default): page partials combined in-launch by the last arriver; 0: second kernel */
+#define LSK_OPT_FLASH_PREFILL 5   /* 1 (default): prompt rows use the flash-shaped prefill attention kernel; 0: 16-row decode passes */
 #define LSK_OPT_FUSED_OPROJ 4     /* 1: attention and o_proj as one role-pipelined launch (rows <= 8); default 0 (measured neutral) */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
 /* Final RMSNorm + lm_head (+ greedy argmax) over rows [row_base, row_base+m)

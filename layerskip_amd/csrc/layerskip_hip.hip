@@ -208,6 +208,7 @@ struct lsk_engine {
     int* heads_done = nullptr;    // monotonic: += n_heads per fused attention+o_proj launch
     int heads_epoch = 0;          // fused launches since the last reset
     bool fused_attn = true;
+    bool flash_prefill = true;    // prompt rows: one flash-shaped attention launch per layer instead of rows/16 decode launches
     bool fused_oproj = false;     // measured neutral at 7B (15.7 us fused vs 8.9 + 6.3 + gap): the seam is a latency chain
     bf16_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]
     bf16_t* kv_pool = nullptr;
@@ -706,9 +707,20 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
             p.kv_len = kvp; p.pos_off = 0;
             LSK_TRY(launch_big<EPI_QKV>(p, st));
         }
-        for (int r0 = 0; r0 < n; r0 += LSK_MAX_ROWS) {
-            const int m = (n - r0) < LSK_MAX_ROWS ? (n - r0) : LSK_MAX_ROWS;
-            LSK_TRY(launch_attn(e, e->q_bulk + (size_t)r0 * qdim, e->attn_bulk + (size_t)r0 * qdim, kpool, vpool, m, r0, st));
+        if (e->flash_prefill) {
+            AttnPrefillParams ap{};
+            ap.q = e->q_bulk; ap.ldq = qdim; ap.out = e->attn_bulk; ap.ldo = qdim; ap.kpool = kpool; ap.vpool = vpool;
+            ap.block_table = e->block_table; ap.n_kv = c.n_kv_heads; ap.group = c.n_heads / c.n_kv_heads; ap.rows = n;
+            ap.kv_len = kvp; ap.pos_off = 0; ap.scale_log2e = (float)((1.0 / sqrt((double)c.head_dim)) * 1.4426950408889634);
+            const dim3 grid(c.n_heads, (n + 15) / 16), block(LSK_ATTN_THREADS);
+            if (c.head_dim == 128) hipLaunchKernelGGL((lsk_attn_prefill_kernel<128>), grid, block, 0, st, ap);
+            else hipLaunchKernelGGL((lsk_attn_prefill_kernel<64>), grid, block, 0, st, ap);
+            HIP_OK(hipGetLastError());
+        } else {
+            for (int r0 = 0; r0 < n; r0 += LSK_MAX_ROWS) {
+                const int m = (n - r0) < LSK_MAX_ROWS ? (n - r0) : LSK_MAX_ROWS;
+                LSK_TRY(launch_attn(e, e->q_bulk + (size_t)r0 * qdim, e->attn_bulk + (size_t)r0 * qdim, kpool, vpool, m, r0, st));
+            }
         }
         {
             BigGemmParams p{};
@@ -1045,6 +1057,7 @@ extern "C" int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t valu
         case LSK_OPT_TARGET_WGS: e->target_wgs = value > 0 ? value : 256; return 0;
         case LSK_OPT_FUSED_ATTN: e->fused_attn = value != 0; return 0;
         case LSK_OPT_FUSED_OPROJ: e->fused_oproj = value != 0; return 0;
+        case LSK_OPT_FLASH_PREFILL: e->flash_prefill = value != 0; return 0;
         default: return lsk_fail("unknown option %d", option);
     }
 }

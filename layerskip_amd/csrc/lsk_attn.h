@@ -275,3 +275,151 @@ __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineP
     }
     p.out[(size_t)row * p.ldo + head * HD + d] = f2bf(a / l);
 }
+
+// ---- prompt-prefill attention: 16 query rows x all visible keys per workgroup, online softmax (flash shape) ----
+// grid = (n_heads, ceil(rows / 16)), block = 4 waves.  Wave w walks KV pages w, w+4, ... of its head in 32-key
+// sub-blocks: K / V^T fragments straight from the pages (same layouts as the decode kernel), S = QK^T and
+// O += P V on MFMA, running (max, sum) per row with one rescale of O per sub-block, P rounded to bf16 through
+// 1 KiB of LDS per wave.  The 4 waves are merged in a fixed order at the end.  One launch per layer replaces the
+// rows/16 launches of the decode kernel; only prompt rows that are not decision rows go through it.
+struct AttnPrefillParams {
+    const bf16_t* q;        // [rows][ldq]
+    int ldq;
+    bf16_t* out;            // [rows][ldo]
+    int ldo;
+    const bf16_t* kpool;
+    const bf16_t* vpool;
+    const int* block_table;
+    int n_kv;
+    int group;
+    int rows;               // query rows; row r sits at position *kv_len + pos_off + r
+    const int* kv_len;
+    int pos_off;
+    float scale_log2e;
+};
+
+template <int HD>
+__global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(const AttnPrefillParams p) {
+    constexpr int KS = HD / 32;
+    constexpr int DT = HD / 16;
+    constexpr int PSTRIDE = HD + 2;
+    constexpr int PB_STRIDE = 80;
+    __shared__ __attribute__((aligned(16))) unsigned char pbuf[LSK_ATTN_WAVES * 16 * PB_STRIDE];
+    __shared__ float sm[LSK_ATTN_WAVES * 16 * PSTRIDE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.x;
+    const int r0 = blockIdx.y * 16;
+    const int kvh = head / p.group;
+    const int c16 = lane & 15;
+    const int g = lane >> 4;
+    const int base_pos = *p.kv_len + p.pos_off + r0;          // position of this workgroup's first row
+    const int M = min(16, p.rows - r0);
+    const int last_key = base_pos + M - 1;
+    const int n_pages = last_key / LSK_ATTN_PAGE + 1;
+
+    const bf16_t* qp = p.q + (size_t)(r0 + min(c16, M - 1)) * p.ldq + head * HD + g * 8;
+    bf16x8 qa[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qa[ks] = *(const bf16x8*)(qp + ks * 32);
+
+    float mrun[4], lrun[4];
+    f32x4 o[DT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrun[r] = LSK_ATTN_NEG; lrun[r] = 0.f; }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned char* pw = pbuf + w * 16 * PB_STRIDE;
+
+    for (int pg = w; pg < n_pages; pg += LSK_ATTN_WAVES) {
+        const int page = p.block_table[pg];
+        const size_t head_base = ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD;
+        for (int sb = 0; sb < 4; ++sb) {
+            const int key0 = pg * LSK_ATTN_PAGE + sb * 32;
+            if (key0 > last_key) break;
+            const bf16_t* kp = p.kpool + head_base + (size_t)(sb * 32 + c16) * HD + g * 8;
+            const bf16_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + sb * 32 + g * 8;
+            bf16x8 kb[2][KS], vb[DT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kb[0][ks] = *(const bf16x8*)(kp + ks * 32);
+                kb[1][ks] = *(const bf16x8*)(kp + 16 * HD + ks * 32);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const bf16x8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[0][ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[1][ks], s1, 0, 0, 0);
+            }
+            const int keyA = key0 + c16;
+            float alpha[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = g * 4 + r;
+                const int lim = base_pos + row;
+                const bool ok0 = (row < M) && (keyA <= lim);
+                const bool ok1 = (row < M) && (keyA + 16 <= lim);
+                const float a0 = ok0 ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
+                const float a1 = ok1 ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
+                float m = fmaxf(a0, a1);
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                const float mn = fmaxf(mrun[r], m);
+                alpha[r] = __builtin_amdgcn_exp2f(mrun[r] - mn);
+                const float p0 = ok0 ? __builtin_amdgcn_exp2f(a0 - mn) : 0.f;
+                const float p1 = ok1 ? __builtin_amdgcn_exp2f(a1 - mn) : 0.f;
+                float l = p0 + p1;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+                lrun[r] = lrun[r] * alpha[r] + l;
+                mrun[r] = mn;
+                *(bf16_t*)(pw + row * PB_STRIDE + c16 * 2) = f2bf(p0);
+                *(bf16_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2bf(p1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const bf16x8 pa = *(const bf16x8*)(pw + c16 * PB_STRIDE + g * 16);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha[r];
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb[dt], o[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();     // P of the next sub-block must not overwrite before the read above
+        }
+    }
+    float* dst = sm + (size_t)w * 16 * PSTRIDE;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(g * 4 + r) * PSTRIDE + dt * 16 + c16] = o[dt][r];
+    if (c16 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dst[(g * 4 + r) * PSTRIDE + HD] = mrun[r];
+            dst[(g * 4 + r) * PSTRIDE + HD + 1] = lrun[r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < M * HD; e += LSK_ATTN_THREADS) {
+        const int r = e / HD;
+        const int d = e - r * HD;
+        float m = LSK_ATTN_NEG;
+#pragma unroll
+        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + r) * PSTRIDE + HD]);
+        float a = 0.f, l = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
+            const float* src = sm + (ww * 16 + r) * PSTRIDE;
+            const float f = __builtin_amdgcn_exp2f(src[HD] - m);
+            a += src[d] * f;
+            l += src[HD + 1] * f;
+        }
+        p.out[(size_t)(r0 + r) * p.ldo + head * HD + d] = f2bf(a / l);
+    }
+}

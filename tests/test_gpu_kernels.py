@@ -248,3 +248,31 @@ def test_engine_grows_context_on_demand(gpu_device):
     assert eng.max_ctx >= 200 + 40 and eng.max_prompt >= 200
     b = strat.generate_token_ids(model, prompt, [cfg.vocab_size], gen)
     assert a.predicted_tokens == b.predicted_tokens and len(a.predicted_tokens) == 40
+
+
+@pytest.mark.parametrize("shape,n", [("tiny-gqa", 301), ("tiny-d64", 150), ("tiny-mha", 64)])
+def test_flash_prefill_attention_matches_decode_attention(gpu_device, shape, n):
+    """lsk_attn_prefill_kernel (one launch per layer, online softmax over all visible pages) vs rows/16
+    launches of the split-KV decode kernel inside the same MFMA prefill path: same rounding points, different
+    summation order -> hidden states equal up to bf16-ulp noise; logits rows nearly identical."""
+    from layerskip_amd import _lib, synthetic
+    from layerskip_amd.engine import BUF_BULK, HipEngine
+    cfg = synthetic.make_config(shape)
+    model = synthetic.build_model(cfg, seed=5, exit_layer=2, late_damping=0.1).to(gpu_device)
+    eng = HipEngine(model, max_ctx=512, max_prompt=320)
+    eng.set_option(_lib.LSK_OPT_BIG_THRESHOLD, 1)
+    ids = synthetic.make_prompt(cfg.vocab_size, n, 21)
+    outs = []
+    for flash in (0, 1):
+        eng.set_option(_lib.LSK_OPT_FLASH_PREFILL, flash)
+        eng.reset()
+        eng.embed_rows(ids, BUF_BULK, 0)
+        eng.run_bulk(n, 0, eng.num_layers)
+        outs.append(eng.read_rows(BUF_BULK, 0, n).float())
+    torch.cuda.synchronize()
+    a, b = outs
+    assert torch.isfinite(b).all()
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 0.03 * scale
+    assert (a - b).abs().mean().item() <= 0.003 * scale
+    eng.close()
