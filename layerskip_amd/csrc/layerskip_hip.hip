@@ -679,12 +679,18 @@ static int embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, bf16_t* d
     return 0;
 }
 
-template <int EPI>
+template <int EPI, int NTW>
 static int launch_big(BigGemmParams& p, hipStream_t st) {
-    const dim3 grid((p.M + LSK_BIG_BM - 1) / LSK_BIG_BM, (p.n_tiles + 7) / 8);
-    hipLaunchKernelGGL((lsk_gemm_big_kernel<EPI>), grid, dim3(LSK_BIG_THREADS), 0, st, p);
+    const dim3 grid((p.M + LSK_BIG_BM - 1) / LSK_BIG_BM, (p.n_tiles + 4 * NTW - 1) / (4 * NTW));
+    hipLaunchKernelGGL((lsk_gemm_big_kernel<EPI, NTW>), grid, dim3(LSK_BIG_THREADS), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+// N = hidden projections: 128-column tiles only when they already give >= 256 workgroups, else 64-column tiles
+static int launch_big_resid(BigGemmParams& p, hipStream_t st) {
+    const int wgs128 = ((p.M + LSK_BIG_BM - 1) / LSK_BIG_BM) * ((p.n_tiles + 7) / 8);
+    return wgs128 >= 256 ? launch_big<EPI_RESID, 2>(p, st) : launch_big<EPI_RESID, 1>(p, st);
 }
 
 // Prompt rows [0, n) of the bulk buffer through layers [lb, le) with the MFMA-tiled prefill kernels.
@@ -705,7 +711,7 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
             p.q_out = e->q_bulk; p.ldq = qdim; p.kpool = kpool; p.vpool = vpool; p.block_table = e->block_table; p.page_size = c.page_size;
             p.n_heads = c.n_heads; p.n_kv = c.n_kv_heads; p.head_dim = c.head_dim; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
             p.kv_len = kvp; p.pos_off = 0;
-            LSK_TRY(launch_big<EPI_QKV>(p, st));
+            LSK_TRY((launch_big<EPI_QKV, 2>(p, st)));
         }
         if (e->flash_prefill) {
             AttnPrefillParams ap{};
@@ -726,7 +732,7 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
             BigGemmParams p{};
             p.x = e->attn_bulk; p.ldx = qdim; p.M = n; p.K = qdim; p.wp = lw.wo; p.N = c.hidden; p.n_tiles = p.N / 16;
             p.h = e->hbulk; p.ldh = c.hidden;
-            LSK_TRY(launch_big<EPI_RESID>(p, st));
+            LSK_TRY(launch_big_resid(p, st));
         }
         hipLaunchKernelGGL(lsk_rmsnorm_rows_kernel, dim3(n), dim3(256), 0, st, e->hbulk, c.hidden, lw.norm2, c.rms_eps, c.hidden, e->xn_bulk, c.hidden);
         HIP_OK(hipGetLastError());
@@ -734,13 +740,13 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
             BigGemmParams p{};
             p.x = e->xn_bulk; p.ldx = c.hidden; p.M = n; p.K = c.hidden; p.wp = lw.wgu; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
             p.act = e->act_bulk; p.ldact = c.intermediate;
-            LSK_TRY(launch_big<EPI_SWIGLU>(p, st));
+            LSK_TRY((launch_big<EPI_SWIGLU, 2>(p, st)));
         }
         {
             BigGemmParams p{};
             p.x = e->act_bulk; p.ldx = c.intermediate; p.M = n; p.K = c.intermediate; p.wp = lw.wdown; p.N = c.hidden; p.n_tiles = p.N / 16;
             p.h = e->hbulk; p.ldh = c.hidden;
-            LSK_TRY(launch_big<EPI_RESID>(p, st));
+            LSK_TRY(launch_big_resid(p, st));
         }
     }
     return 0;

@@ -49,18 +49,20 @@ struct BigGemmParams {
     int pos_off;
 };
 
-template <int EPI>
+// NTW = packed 16-column tiles per wave: 2 (128-column workgroup tile; needed by the SwiGLU / RoPE pairs) or
+// 1 (64-column tile: twice the workgroups for the N = hidden projections, which otherwise fill half the chip).
+template <int EPI, int NTW>
 __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const BigGemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * LSK_BIG_BM * LSK_BIG_LDA];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * LSK_BIG_BM;
-    const int T0 = (blockIdx.y * 4 + w) * 2;             // this wave's first packed tile
+    const int T0 = (blockIdx.y * 4 + w) * NTW;           // this wave's first packed tile
     const int ksteps = p.K >> 5;
     const int nkt = p.K / LSK_BIG_BK;
     const bool tile_ok = T0 < p.n_tiles;
-    const bool tile1_ok = T0 + 1 < p.n_tiles;
+    const bool tile1_ok = (NTW == 2) && (T0 + 1 < p.n_tiles);
 
     // A staging: thread -> (row, 64-byte half)
     const int arow = tid >> 1;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
             for (int mt = 0; mt < 8; ++mt) {
                 const bf16x8 a = *(const bf16x8*)(abase + mt * 16 * LSK_BIG_LDA + s * 64);
                 acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[0][s], acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[1][s], acc[mt][1], 0, 0, 0);
+                if (NTW == 2) acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[1][s], acc[mt][1], 0, 0, 0);
             }
         }
         if (more) {
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
     const int rg = lane >> 4;
     if (EPI == EPI_RESID) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             const int n = (T0 + nt) * 16 + c16;
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt)
