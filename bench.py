@@ -135,7 +135,10 @@ def main():
         one(1000 + i)
     barrier()
     t0 = time.perf_counter()
-    results = [one(i) for i in range(args.steps)]
+    results, step_traces = [], []
+    for i in range(args.steps):
+        results.append(one(i))
+        step_traces.append(list(getattr(strategy, "last_steps", [])))   # host bookkeeping only
     barrier()
     elapsed = time.perf_counter() - t0
     tokens = sum(len(r.predicted_tokens) for r in results)
@@ -189,17 +192,17 @@ def main():
         }
         # ---- whole-path decode-bandwidth roofline from the run's own (T_d, n, ctx) ----
         if spec:
-            trace, c, p = [], 0, args.prompt_len
-            produced = 0
-            # re-derive the per-step trace from a traced run (cheap: host bookkeeping only)
-            eng_steps = _trace_steps(strategy, model, synthetic.make_prompt(cfg.vocab_size, args.prompt_len, 0), eos, gen)
-            for (td, n) in eng_steps:
-                trace.append((c, p, td, n))
-                c, p = c + p + n, 1
-                produced += n + 1
-            total_b = step_bytes(cfg, E, args.prompt_len, trace)
+            # bytes of the TIMED generations of this rank, from their own (T_d, n, ctx) traces
+            total_b, produced = 0, 0
+            for steps_i in step_traces:
+                trace, c, p = [], 0, args.prompt_len
+                for (td, n) in steps_i:
+                    trace.append((c, p, td, n))
+                    c, p = c + p + n, 1
+                    produced += n + 1
+                total_b += step_bytes(cfg, E, args.prompt_len, trace)
             floor_s = total_b / (HBM_PEAK_GBS * 1e9)
-            out["path_roofline"] = {"algorithmic_bytes_per_generation": total_b,
+            out["path_roofline"] = {"algorithmic_bytes_per_generation": total_b // max(1, len(step_traces)),
                                     "floor_tokens_per_s_at_8TBs": round(produced / floor_s, 1),
                                     "frac_of_floor": round((value / world) / (produced / floor_s), 4)}
         if not args.no_cpu_baseline and world == 1:        # reported on rank 0 at N = 1 only
@@ -256,12 +259,6 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev):
                        "strategy": "self_speculative", "parallelism": f"pp{world} layer ranges {part}"}}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
-
-
-def _trace_steps(strategy, model, prompt, eos, gen):
-    """(num_drafts, num_matches) of every speculation step of one generation."""
-    strategy.generate_token_ids(model, prompt, eos, gen)
-    return list(strategy.last_steps)
 
 
 def gpu_reference(args, cfg, model, E, S, eos, engine_tps):
