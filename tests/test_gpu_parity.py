@@ -330,3 +330,24 @@ def test_fused_autoregressive_generate_equals_stepwise(gpu_device, name):
     cfg.exit_layer = rec["exit_layer"]            # early-exit-only decoding through the same call
     assert (fused.generate_token_ids(model, rec["prompt"], eos, cfg).predicted_tokens
             == stepwise.generate_token_ids(model, rec["prompt"], eos, cfg).predicted_tokens)
+
+
+def test_long_context_many_pages(gpu_device):
+    """A context of > 8 KV pages (the page-partial combine walks pages in groups of 8) and a prompt longer than
+    the default prefill buffer: speculative == autoregressive in the engine, and both follow the fp32 oracle."""
+    from layerskip_amd import GenerationConfig, synthetic
+    from oracle import llama_oracle as lo
+    cfg = synthetic.make_config("tiny-mha")
+    model_cpu = synthetic.build_model(cfg, seed=21, exit_layer=2, late_damping=0.05)
+    prompt = synthetic.make_prompt(cfg.vocab_size, 1190, 77)
+    eos = [cfg.vocab_size]
+    om = lo.OracleModel.from_hf(model_cpu, dtype=torch.float32)
+    with torch.inference_mode():
+        want = lo.self_speculative_generate(om, prompt, eos, 36, 2, 5)
+    model = model_cpu.to(gpu_device)
+    spec_s, ar_s = _strategies()
+    a = spec_s.generate_token_ids(model, prompt, eos, GenerationConfig(max_steps=36, exit_layer=2, num_speculations=5, sample=False))
+    b = ar_s.generate_token_ids(model, prompt, eos, GenerationConfig(max_steps=36, exit_layer=-1, sample=False))
+    assert a.predicted_tokens == b.predicted_tokens and len(a.predicted_tokens) == 36
+    i = _first_mismatch(a.predicted_tokens, want.predicted_tokens)
+    assert i is None or want.margins[i] < TIE_TOL, (i, want.margins[i])
