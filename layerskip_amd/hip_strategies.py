@@ -88,7 +88,8 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                            streamer=None) -> GenerationStrategyResult:
         engine = get_engine(model, **self.engine_kwargs)
         spec = max(0, int(generation_config.num_speculations))
-        engine.ensure_capacity(len(input_ids) + generation_config.max_steps + spec + 2, len(input_ids))
+        extra_rows = spec if spec > _lib.LSK_MAX_SPEC else 0      # long draft blocks live behind the prompt rows
+        engine.ensure_capacity(len(input_ids) + generation_config.max_steps + spec + 2, len(input_ids) + extra_rows)
         engine.reset()                                            # past_key_values = None
         if (self.fused_generate and not generation_config.sample and not logits_processors and not stopping_criteria
                 and streamer is None and spec <= _lib.LSK_MAX_SPEC and hasattr(engine, "spec_generate")
@@ -138,15 +139,16 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                                 logits_processors=None, stopping_criteria=None, streamer=None):
         engine = get_engine(model, **self.engine_kwargs)
         if past_key_values is None:
-            engine.ensure_capacity(len(input_ids_list) + max(0, num_speculations) + 2, input_ids.shape[1])
+            sp = max(0, num_speculations)
+            engine.ensure_capacity(len(input_ids_list) + sp + 2, input_ids.shape[1] + (sp if sp > _lib.LSK_MAX_SPEC else 0))
             engine.reset()
         spec = max(0, int(num_speculations))
-        if spec > _lib.LSK_MAX_SPEC:
-            raise ValueError(f"num_speculations={spec} > {_lib.LSK_MAX_SPEC} is not supported by the fused verify block")
         if not (1 <= exit_layer < engine.num_layers):
             raise ValueError(f"exit_layer={exit_layer} must be in [1, {engine.num_layers})")
         new_ids = [int(t) for t in input_ids[0].tolist()]
-        if sample or logits_processors:
+        if sample or logits_processors or spec > _lib.LSK_MAX_SPEC:
+            # (more than 15 speculations do not fit the 16-row fused verify block: same kernels, rows walked in
+            #  16-row passes from the host)
             step = self._slow_step(engine, new_ids, spec, exit_layer, eos_token_ids, sample, temperature, top_k, top_p,
                                    logits_processors)
         else:
@@ -189,6 +191,14 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         P, E, L = len(ids), exit_layer, engine.num_layers
         C = engine.kv_len
         dev = engine.device
+        # the step rows (input token + drafts) live in the 16-row step buffer, or -- for more than 15
+        # speculations -- right behind the prompt rows of the bulk buffer
+        if spec <= _lib.LSK_MAX_SPEC:
+            SBUF, SBASE = BUF_STEP, 0
+        else:
+            if P + spec > engine.max_prompt + 16:
+                raise ValueError(f"num_speculations={spec} needs max_prompt >= {P + spec - 16} (engine has {engine.max_prompt})")
+            SBUF, SBASE = BUF_BULK, P - 1
         if P > 1:
             engine.embed_rows(ids[:-1], BUF_BULK, 0)
             engine.run_layers_chunked(BUF_BULK, 0, P - 1, 0, 0, E)
@@ -198,12 +208,12 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         draft_input = torch.tensor([ids], device=dev)
         j = 0
         while True:
-            engine.embed_rows([tok], BUF_STEP, j)
-            engine.run_layers(BUF_STEP, j, 1, P - 1 + j, 0, E)
+            engine.embed_rows([tok], SBUF, SBASE + j)
+            engine.run_layers(SBUF, SBASE + j, 1, P - 1 + j, 0, E)
             if j >= spec:
                 break
             # forward_early returns logits for every input row (LMU:271-273): the prompt rows on call 0
-            blocks = ([(BUF_BULK, 0, P - 1)] if (j == 0 and P > 1 and processors) else []) + [(BUF_STEP, j, 1)]
+            blocks = ([(BUF_BULK, 0, P - 1)] if (j == 0 and P > 1 and processors) else []) + [(SBUF, SBASE + j, 1)]
             logits = self._logits_rows(engine, blocks)
             if processors:
                 logits = processors(draft_input, logits)
@@ -215,15 +225,15 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
             draft_input = torch.tensor([[tok]], device=dev)
             j += 1
             if tok in eos:
-                engine.embed_rows([tok], BUF_STEP, j)
-                engine.run_layers(BUF_STEP, j, 1, P - 1 + j, 0, E)
+                engine.embed_rows([tok], SBUF, SBASE + j)
+                engine.run_layers(SBUF, SBASE + j, 1, P - 1 + j, 0, E)
                 break
         td = len(drafts)
         if P > 1:
             engine.run_layers_chunked(BUF_BULK, 0, P - 1, 0, E, L)
-        engine.run_layers(BUF_STEP, 0, td + 1, P - 1, E, L)
+        engine.run_layers_chunked(SBUF, SBASE, td + 1, P - 1, E, L)
         prefill = torch.tensor([ids + drafts], device=dev)
-        blocks = ([(BUF_BULK, 0, P - 1)] if (P > 1 and processors) else []) + [(BUF_STEP, 0, td + 1)]
+        blocks = ([(BUF_BULK, 0, P - 1)] if (P > 1 and processors) else []) + [(SBUF, SBASE, td + 1)]
         logits = self._logits_rows(engine, blocks)
         if processors:
             logits = processors(prefill, logits)

@@ -351,3 +351,18 @@ def test_long_context_many_pages(gpu_device):
     assert a.predicted_tokens == b.predicted_tokens and len(a.predicted_tokens) == 36
     i = _first_mismatch(a.predicted_tokens, want.predicted_tokens)
     assert i is None or want.margins[i] < TIE_TOL, (i, want.margins[i])
+
+
+def test_more_than_15_speculations(gpu_device):
+    """num_speculations beyond the 16-row fused verify block: host-walked 16-row passes, same kernels."""
+    from layerskip_amd import GenerationConfig, synthetic
+    cfg = synthetic.make_config("tiny-gqa")
+    model = synthetic.build_model(cfg, seed=13, exit_layer=3, late_damping=0.02).to(gpu_device)
+    prompt = synthetic.make_prompt(cfg.vocab_size, 45, 5)
+    eos = [cfg.vocab_size]
+    spec_s, ar_s = _strategies()
+    a = spec_s.generate_token_ids(model, prompt, eos, GenerationConfig(max_steps=50, exit_layer=3, num_speculations=21, sample=False))
+    b = ar_s.generate_token_ids(model, prompt, eos, GenerationConfig(max_steps=50, exit_layer=-1, sample=False))
+    c = spec_s.generate_token_ids(model, prompt, eos, GenerationConfig(max_steps=50, exit_layer=3, num_speculations=6, sample=False))
+    assert a.predicted_tokens == b.predicted_tokens == c.predicted_tokens
+    assert 0.0 <= a.acceptance_rate <= 1.0

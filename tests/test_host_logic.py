@@ -145,5 +145,3 @@ def test_argument_validation(fake):
     strat = hip_strategies.HipSelfSpeculativeGenerationStrategy()
     with pytest.raises(ValueError):
         strat.generate_token_ids(model, rec["prompt"], rec["eos_token_ids"], _cfg(rec, exit_layer=99))
-    with pytest.raises(ValueError):
-        strat.generate_token_ids(model, rec["prompt"], rec["eos_token_ids"], _cfg(rec, num_speculations=40))
