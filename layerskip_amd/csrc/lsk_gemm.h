@@ -54,7 +54,9 @@ __device__ __forceinline__ UnitInfo lsk_unit_info(int u, int units, int ntl, int
 #define LSK_LDS_BESTI 18432     // [16][16] i32 = 1024
 #define LSK_LDS_X 20480         // M rows of xstride bytes
 
-__host__ __device__ inline int lsk_gemm_xstride(int K) { return (K < LSK_KC_ELEMS ? K : LSK_KC_ELEMS) * 2 + 16; }
+// +32 B per row: the 16-B slot of (row r, k-group g) in a 256-B bank row is (2r + g) mod 16, a bijection inside every
+// 16-lane service group of ds_read_b128 (with +16 B it was r + g: 2-way conflicts, SQ_LDS_BANK_CONFLICT 34 % at M = 7)
+__host__ __device__ inline int lsk_gemm_xstride(int K) { return (K < LSK_KC_ELEMS ? K : LSK_KC_ELEMS) * 2 + 32; }
 __host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS_X + (size_t)M * lsk_gemm_xstride(K); }
 
 // Activation staging is split in two so that no global load of x ever sits BEHIND the weight ring in a

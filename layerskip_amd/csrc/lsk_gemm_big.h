@@ -17,7 +17,7 @@
 #define LSK_BIG_BM 128
 #define LSK_BIG_BK 64
 #define LSK_BIG_THREADS 256
-#define LSK_BIG_LDA 144          // bytes per LDS row: 64 bf16 + 16 B pad
+#define LSK_BIG_LDA 160          // bytes per LDS row: 64 bf16 + 32 B pad (slot (10r + g) mod 16: conflict-free A-fragment reads)
 
 struct BigGemmParams {
     const bf16_t* x;        // [M][ldx]
