@@ -11,11 +11,14 @@ Same constructor (none), same ``generate_token_ids`` / ``single_step_speculation
 result objects, same corner-case behaviour (EOS dropped and truncating, ``max_steps`` clamp of the
 speculation count, ``ZeroDivisionError`` when no draft was ever made, falsy-when-empty processors).
 
-Two execution paths:
-  fast  greedy, no logits processors: ONE C-ABI call per speculation step (`lsk_spec_step`): draft
-        loop, verify, ballot acceptance and KV rollback all stay on the device, one sync per step.
-  slow  logits processors and/or sampling: the same kernels driven row-block by row-block with the
-        logits materialised as a tensor so the user's callables see what the reference shows them.
+Execution paths:
+  fused greedy, no logits processors / stopping criteria / streamer: the whole generation is ONE C-ABI call
+        (`lsk_spec_generate` / `lsk_ar_generate`), speculation steps pipelined on the stream;
+  step  greedy with a streamer or stopping criteria: ONE C-ABI call per speculation step (`lsk_spec_step`):
+        draft loop, verify, ballot acceptance and KV rollback all stay on the device, one sync per step;
+  slow  logits processors, sampling or more than 15 speculations: the same kernels driven row-block by
+        row-block with the logits materialised as a tensor so the user's callables see what the reference
+        shows them.
 """
 from __future__ import annotations
 
@@ -201,7 +204,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
             SBUF, SBASE = BUF_BULK, P - 1
         if P > 1:
             engine.embed_rows(ids[:-1], BUF_BULK, 0)
-            engine.run_layers_chunked(BUF_BULK, 0, P - 1, 0, 0, E)
+            engine.run_bulk(P - 1, 0, E)            # same prefill kernels as the fused path
         drafts: List[int] = []
         draft_probs = []
         tok = ids[-1]
@@ -230,7 +233,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                 break
         td = len(drafts)
         if P > 1:
-            engine.run_layers_chunked(BUF_BULK, 0, P - 1, 0, E, L)
+            engine.run_bulk(P - 1, E, L)
         engine.run_layers_chunked(SBUF, SBASE, td + 1, P - 1, E, L)
         prefill = torch.tensor([ids + drafts], device=dev)
         blocks = ([(BUF_BULK, 0, P - 1)] if (P > 1 and processors) else []) + [(SBUF, SBASE, td + 1)]
@@ -305,7 +308,7 @@ class HipAutoRegressiveGenerationStrategy(GenerationStrategy):
         C = engine.kv_len
         if P > 1:
             engine.embed_rows(ids[:-1], BUF_BULK, 0)
-            engine.run_layers_chunked(BUF_BULK, 0, P - 1, 0, 0, layer_end)
+            engine.run_bulk(P - 1, 0, layer_end)
         engine.embed_rows(ids[-1:], BUF_STEP, 0)
         engine.run_layers(BUF_STEP, 0, 1, P - 1, 0, layer_end)
         blocks = ([(BUF_BULK, 0, P - 1)] if (P > 1 and processors) else []) + [(BUF_STEP, 0, 1)]

@@ -130,10 +130,12 @@ def test_step_api_matches_reference_shape(gpu_device):
     assert past.length == len(ids) + len(output_ids) - 1
 
 
-def test_slow_path_equals_fast_path(gpu_device):
-    """A no-op logits processor forces the materialised-logits path; greedy ids must not change."""
+@pytest.mark.parametrize("name", ["tiny_mha_s1", "tiny_gqa_long"])
+def test_slow_path_equals_fast_path(gpu_device, name):
+    """A no-op logits processor forces the materialised-logits path; greedy ids must not change
+    (short prompt: 16-row prefill passes; 300-token prompt: the MFMA prefill kernels in both paths)."""
     import transformers
-    rec = load_golden("tiny_mha_s1")
+    rec = load_golden(name)
     model = _model(rec, gpu_device)
     spec, ar = _strategies()
     fast = spec.generate_token_ids(model, rec["prompt"], rec["eos_token_ids"], _config(rec, "self_speculative"))
