@@ -18,8 +18,10 @@ that this restatement reproduces them bit-for-bit on CPU (token ids, acceptance
 counters, logits) in fp32 and bf16; the resulting vectors are committed under
 ``tests/golden/`` and re-checked by ``tests/test_oracle_golden.py`` on every box.
 
-Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may
-import this module.  The product (``layerskip_amd``) never does.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s baseline legs (``cpu_baseline``, and
+the optional ``--gpu-reference`` leg that runs this same restatement with its tensors on the GPU, i.e. the
+reference's torch-ROCm eager path) may import this module -- always as the checker / the thing timed BESIDE the
+engine, never as part of it.  The product (``layerskip_amd``) never imports it.
 """
 from __future__ import annotations
 
