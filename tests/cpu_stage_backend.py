@@ -45,6 +45,16 @@ class CpuStageBackend:
                               n_heads=cfg.num_attention_heads, n_kv_heads=cfg.num_key_value_heads, head_dim=hd,
                               eps=float(cfg.rms_norm_eps), attn_impl="sdpa", dtype=torch.float32)
 
+    max_prompt = 4000
+
+    def ensure_capacity(self, total_tokens, prompt_len):
+        pass
+
+    def run_layers_chunked(self, buffer, row_base, n, pos_offset, layer_begin, layer_end):
+        for r0 in range(0, n, 16):
+            m = min(16, n - r0)
+            self.run_layers(buffer, row_base + r0, m, pos_offset + r0, layer_begin, layer_end)
+
     # ---- state
     def reset(self):
         self.kv = [None] * self.num_layers
