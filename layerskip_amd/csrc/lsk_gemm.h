@@ -204,6 +204,13 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     f32x4 own0 = {0.f, 0.f, 0.f, 0.f};
     f32x4 own1 = {0.f, 0.f, 0.f, 0.f};
 
+    // A wave owns the same k-steps of every tile of a K-chunk, so its 16 A fragments are read from LDS once per
+    // chunk and stay in VGPRs: the unit loop then waits on the weight stream only (with a ds_read in front of
+    // every MFMA the LDS latency was exposed ~8x per unit and the ring refills queued up behind it).
+    bf16x8 afr[LSK_SPW];
+#pragma unroll
+    for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const bf16x8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
+
     for (int u = 0; u < units; ++u) {
         const UnitInfo nxt = lsk_unit_info(u + 1, units, ntl, ksteps, tile0, w, lane);
         if (nchunks > 1 && cur.tl == 0 && u > 0) {
@@ -213,13 +220,13 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             if (cur.c + 1 < nchunks)
                 lsk_load_chunk<PRO, MB, WAIT>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
             __syncthreads();
+#pragma unroll
+            for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const bf16x8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < LSK_SPW; ++s) {
-            const int ksl = min(cur.ks0 + s, cur.steps_c - 1);
-            const bf16x8 a = *(const bf16x8*)(xa + ksl * 64);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, ring[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[s], __builtin_bit_cast(bf16x8, ring[s]), acc, 0, 0, 0);
             const unsigned off = (s < nxt.nvalid) ? nxt.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
             ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
             // (hipcc sinks these refills into bursts behind later MFMAs, so the ring runs ~8-16 deep; pinning
