@@ -123,13 +123,11 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
         const float a0 = ok0 ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
         const float a1 = ok1 ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
         float m = fmaxf(a0, a1);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        m = row16_max(m);
         const float p0 = ok0 ? __builtin_amdgcn_exp2f(a0 - m) : 0.f;
         const float p1 = ok1 ? __builtin_amdgcn_exp2f(a1 - m) : 0.f;
         float l = p0 + p1;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+        l = row16_sum(l);
         mrow[r] = m;
         lrow[r] = l;
         *(bf16_t*)(pw + row * PB_STRIDE + c16 * 2) = f2bf(p0);
@@ -366,15 +364,13 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(cons
                 const float a0 = ok0 ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
                 const float a1 = ok1 ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
                 float m = fmaxf(a0, a1);
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                m = row16_max(m);
                 const float mn = fmaxf(mrun[r], m);
                 alpha[r] = __builtin_amdgcn_exp2f(mrun[r] - mn);
                 const float p0 = ok0 ? __builtin_amdgcn_exp2f(a0 - mn) : 0.f;
                 const float p1 = ok1 ? __builtin_amdgcn_exp2f(a1 - mn) : 0.f;
                 float l = p0 + p1;
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+                l = row16_sum(l);
                 lrun[r] = lrun[r] * alpha[r] + l;
                 mrun[r] = mn;
                 *(bf16_t*)(pw + row * PB_STRIDE + c16 * 2) = f2bf(p0);

@@ -22,10 +22,48 @@ __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }   // round
 // bf16 modules materialise a tensor).
 __device__ __forceinline__ float rbf(float v) { return (float)((bf16_t)v); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane traffic goes through DPP (VALU, a few cycles) instead of __shfl_xor, which hipcc lowers to
+// ds_bpermute_b32: an LDS-pipe round trip of ~100 cycles per step that sat 6-deep on every reduction of the
+// RMSNorm prologue and 8-deep on every softmax row of the (latency-bound) attention kernels.
+template <int CTRL>
+__device__ __forceinline__ float lsk_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int lsk_dpp(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+#define LSK_ROW_ROR(n) (0x120 + (n))      // rotate right inside each row of 16 lanes
+
+// Lane i <-> lane i^8 of the same 16-lane row (a rotation by 8 of a row of 16 is exactly that exchange).
+__device__ __forceinline__ float row_xor8(float v) { return lsk_dpp<LSK_ROW_ROR(8)>(v); }
+
+// All-reduce over each 16-lane row.  Rotations by 8, 4, 2, 1 pair the same partial sums as the xor butterfly
+// (after the step of stride s the value is periodic with period s), so the result is bit-identical to it.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += lsk_dpp<LSK_ROW_ROR(8)>(v);
+    v += lsk_dpp<LSK_ROW_ROR(4)>(v);
+    v += lsk_dpp<LSK_ROW_ROR(2)>(v);
+    v += lsk_dpp<LSK_ROW_ROR(1)>(v);
     return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, lsk_dpp<LSK_ROW_ROR(8)>(v));
+    v = fmaxf(v, lsk_dpp<LSK_ROW_ROR(4)>(v));
+    v = fmaxf(v, lsk_dpp<LSK_ROW_ROR(2)>(v));
+    v = fmaxf(v, lsk_dpp<LSK_ROW_ROR(1)>(v));
+    return v;
+}
+
+// Sum over the 64 lanes of a wave, same value (wave-uniform) in every lane: four row sums, then the four row
+// totals through v_readlane in a fixed order.
+__device__ __forceinline__ float wave_sum(float v) {
+    const int r = __builtin_bit_cast(int, row16_sum(v));
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // ---- projection (skinny GEMM) -----------------------------------------------------------------

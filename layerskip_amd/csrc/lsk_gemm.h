@@ -307,7 +307,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                 float v = rbf(own0[i]);
                 int feat;
                 if (kind != 2) {
-                    const float partner = __shfl_xor(v, 8, 64);
+                    const float partner = row_xor8(v);
                     const int j = tt * 8 + (c16 & 7);
                     const float cs = bf2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
                     const float sn = bf2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);

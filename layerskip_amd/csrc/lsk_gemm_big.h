@@ -184,7 +184,7 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
                     float v = rbf(acc[mt][nt][i]);
                     int feat;
                     if (kind != 2) {
-                        const float partner = __shfl_xor(v, 8, 64);
+                        const float partner = row_xor8(v);
                         const int j = tt * 8 + (c16 & 7);
                         const float cs = bf2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
                         const float sn = bf2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
