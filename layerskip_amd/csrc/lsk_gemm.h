@@ -133,7 +133,51 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
 
-    // ---- activations first (they must not queue behind the weight ring), then fill the ring ----
+    // ---- epilogue operands first: everything the owner waves will need after the last MFMA that does not depend on
+    //      the product (residual values, RoPE cos/sin, KV page ids) is requested before the weight stream, so the
+    //      tail of the launch is arithmetic + stores instead of one or two dependent global-load round trips ----
+    const int c16 = lane & 15;
+    const int rg = lane >> 4;
+    const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : ntl;
+    const bool is_owner = w < n_owned;
+    float pre_a[4] = {0.f, 0.f, 0.f, 0.f};      // RESID: residual values | QKV: cos
+    float pre_b[4] = {0.f, 0.f, 0.f, 0.f};      // QKV: sin
+    int pre_pg[4] = {0, 0, 0, 0};               // QKV: KV page of each row's position
+    int base_pos = 0;
+    if (EPI == EPI_RESID) {
+        if (is_owner) {
+            const int n = (tile0 + w) * 16 + c16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rg * 4 + i;
+                if (row < M && n < p.N) pre_a[i] = bf2f(p.h[(size_t)row * p.ldh + n]);
+            }
+        }
+    } else if (EPI == EPI_QKV) {
+        base_pos = *p.kv_len + p.pos_off;
+        if (is_owner) {
+            const int hd = p.head_dim;
+            const int tph = hd >> 4;
+            const int T = tile0 + w;
+            const int nq_t = p.n_heads * tph;
+            const int nk_t = p.n_kv * tph;
+            const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);
+            const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
+            const int tt = TT - (TT / tph) * tph;
+            const int j = tt * 8 + (c16 & 7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pos = base_pos + min(rg * 4 + i, M - 1);
+                if (kind != 2) {
+                    pre_a[i] = bf2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
+                    pre_b[i] = bf2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
+                }
+                if (kind != 0) pre_pg[i] = p.block_table[pos / p.page_size];
+            }
+        }
+    }
+
+    // ---- activations next (they must not queue behind the weight ring), then fill the ring ----
     UnitInfo cur = lsk_unit_info(0, units, ntl, ksteps, tile0, w, lane);
     bf16x8 xr[MB];
     bf16x8 nw;
@@ -248,10 +292,6 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     }
 
     // ---- epilogue: owner wave `ow` holds tile (tile0 + ow) [pair ow for SWIGLU] in C layout ----
-    const int c16 = lane & 15;
-    const int rg = lane >> 4;
-    const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : ntl;
-    const bool is_owner = w < n_owned;
 
     if (EPI == EPI_F32) {
         if (is_owner) {
@@ -268,10 +308,8 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
-                if (row < M && n < p.N) {
-                    bf16_t* hp = p.h + (size_t)row * p.ldh + n;
-                    *hp = f2bf(bf2f(*hp) + rbf(own0[i]));           // residual + Linear(...) in model dtype
-                }
+                if (row < M && n < p.N)
+                    p.h[(size_t)row * p.ldh + n] = f2bf(pre_a[i] + rbf(own0[i]));   // residual + Linear(...) in model dtype
             }
         }
     } else if (EPI == EPI_SWIGLU) {
@@ -299,7 +337,6 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
             const int head = TT / tph;
             const int tt = TT - head * tph;
-            const int base_pos = *p.kv_len + p.pos_off;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
@@ -309,8 +346,8 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                 if (kind != 2) {
                     const float partner = row_xor8(v);
                     const int j = tt * 8 + (c16 & 7);
-                    const float cs = bf2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
-                    const float sn = bf2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
+                    const float cs = pre_a[i];
+                    const float sn = pre_b[i];
                     const float a = rbf(v * cs);                               // q * cos
                     const float b = rbf((c16 < 8 ? -partner : partner) * sn);  // rotate_half(q) * sin
                     v = rbf(a + b);
@@ -322,7 +359,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                     if (kind == 0) {
                         p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2bf(v);
                     } else {
-                        const int page = p.block_table[pos / p.page_size];
+                        const int page = pre_pg[i];
                         const int slot = pos % p.page_size;
                         const size_t hb = ((size_t)page * p.n_kv + head) * p.page_size * hd;
                         if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2bf(v);        // K page  [slot][d]
