@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -298,6 +299,7 @@ extern "C" int lsk_kv_pool_bytes(const lsk_config* cfg, size_t* out_bytes) {
 }
 
 extern "C" int lsk_packed_bytes(int32_t n_rows, int32_t k, size_t* out_bytes) {
+    if (!out_bytes) return lsk_fail("lsk_packed_bytes: null out");
     if (n_rows <= 0 || k <= 0 || (k % 32)) return lsk_fail("lsk_packed_bytes: n_rows=%d k=%d (k must be a multiple of 32)", n_rows, k);
     *out_bytes = (size_t)((n_rows + 15) / 16) * 16 * (size_t)k * 2;
     return 0;
@@ -327,9 +329,15 @@ static int set_gemm_attr() {
     return 0;
 }
 
+// hipFuncSetAttribute is per device: done once per device of this process, under a lock (engines may be created from
+// several host threads; the supported deployment is one process per GPU, but nothing here relies on it).
 static int init_kernel_attrs() {
-    static bool done = false;
-    if (done) return 0;
+    static std::mutex mu;
+    static unsigned long long done_mask = 0;
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && (done_mask >> dev) & 1ull) return 0;
     LSK_TRY((set_gemm_attr<PRO_PLAIN, EPI_F32>()));
     LSK_TRY((set_gemm_attr<PRO_RMS, EPI_F32>()));
     LSK_TRY((set_gemm_attr<PRO_PLAIN, EPI_RESID>()));
@@ -340,9 +348,11 @@ static int init_kernel_attrs() {
     HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
     HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
     HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-    done = true;
+    if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
     return 0;
 }
+
+extern "C" int lsk_engine_destroy(lsk_engine* e);
 
 extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t workspace_bytes, void* kv_pool, size_t kv_pool_bytes,
                                  lsk_engine** out) {
@@ -399,7 +409,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 128, hipHostMallocDefault);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[0], hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[1], hipEventDisableTiming);
-    if (err != hipSuccess) { delete e; return lsk_fail("engine init copy failed: %s", hipGetErrorString(err)); }
+    if (err != hipSuccess) { (void)lsk_engine_destroy(e); return lsk_fail("engine init failed: %s", hipGetErrorString(err)); }
     *out = e;
     return 0;
 }
@@ -496,6 +506,8 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
     const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
     if (lds > kMaxGemmLds) return lsk_fail("gemm LDS %zu exceeds %zu", lds, kMaxGemmLds);
+    // 32-bit buffer offsets; the out-of-range sentinel of ragged ring slots must stay beyond the descriptor's range
+    if ((size_t)p.n_tiles * 16 * (size_t)p.K * 2 >= (size_t)LSK_OOB_OFFSET) return lsk_fail("packed weight of %d x %d exceeds the 32-bit buffer range", p.n_tiles * 16, p.K);
     if (ev_start != nullptr) {
         // profiling: the events are bound to THIS dispatch's own begin / end timestamps (what rocprofv3 reports)
         if (p.M == 1) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
@@ -1128,24 +1140,27 @@ extern "C" int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t 
     LSK_TRY(layers_bound(e, 0, e->cfg.num_layers));
     hipStream_t st = (hipStream_t)stream;
     const lsk_config& c = e->cfg;
-    hipEvent_t a, b;
+    hipEvent_t a = nullptr, b = nullptr;
     HIP_OK(hipEventCreate(&a));
-    HIP_OK(hipEventCreate(&b));
-    HIP_OK(hipEventRecord(a, st));
-    for (int i = 0; i < iters; ++i) {
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return lsk_fail("hipEventCreate failed"); }
+    float ms = 0.f;
+    int rc = 0;
+    hipError_t err = hipEventRecord(a, st);
+    for (int i = 0; i < iters && rc == 0 && err == hipSuccess; ++i) {
         const LayerWeights& lw = e->layers[(layer + i) % c.num_layers];
         GemmParams p{};
         p.x = e->hrow; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
         p.wp = lw.wgu; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
         p.norm_w = lw.norm2; p.eps = c.rms_eps; p.act = e->act; p.ldact = c.intermediate;
-        LSK_TRY((launch_gemm<PRO_RMS, EPI_SWIGLU>(p, e->target_wgs, st)));
+        rc = launch_gemm<PRO_RMS, EPI_SWIGLU>(p, e->target_wgs, st);
     }
-    HIP_OK(hipEventRecord(b, st));
-    HIP_OK(hipEventSynchronize(b));
-    float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, a, b));
+    if (rc == 0 && err == hipSuccess) err = hipEventRecord(b, st);
+    if (rc == 0 && err == hipSuccess) err = hipEventSynchronize(b);
+    if (rc == 0 && err == hipSuccess) err = hipEventElapsedTime(&ms, a, b);
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
+    if (rc != 0) return rc;
+    if (err != hipSuccess) return lsk_fail("lsk_time_gateup: %s", hipGetErrorString(err));
     *ms_per_launch = ms / iters;
     return 0;
 }

@@ -49,6 +49,14 @@ def _i32_array(values: Sequence[int]):
 class HipEngine:
     """One engine per (model, device).  Not re-entrant; one caller thread (like the reference)."""
 
+    def _eos_array(self, eos_token_ids: Sequence[int]):
+        """Ids outside the vocabulary can never be produced and are dropped; more than LSK_MAX_EOS real ids is an
+        error (never a silent truncation: the device-side draft cut and the host-side output cut must agree)."""
+        eos = [int(t) for t in eos_token_ids if 0 <= int(t) < self.vocab]
+        if len(eos) > _lib.LSK_MAX_EOS:
+            raise _lib.LskError(f"{len(eos)} eos token ids; the engine supports at most {_lib.LSK_MAX_EOS}")
+        return eos, _i32_array(eos)
+
     def __init__(self, model, max_ctx: int = 2048, max_prompt: int = 1024, page_size: int = 128,
                  target_wgs: int = 0, layer_range: Optional[Sequence[int]] = None, release_weights: bool = False):
         self.lib = _lib.load()
@@ -60,7 +68,15 @@ class HipEngine:
             raise _lib.LskError(f"HipEngine computes in bf16; model dtype is {weight.dtype}")
         if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
             raise _lib.LskError("biased projections are not supported")
-        self.model = model          # keeps the borrowed weights alive
+        # The engine keeps its own references to every tensor it borrows (embedding, norm gains) and copies of the
+        # scalars it needs later, but NOT the model: `get_engine` maps model -> engine weakly, and a strong
+        # reference back to the key would keep both (and ~2x the weights in HBM) alive forever.
+        import weakref
+        self._model_ref = weakref.ref(model)
+        self.rms_eps = float(cfg.rms_norm_eps)
+        rot = model.model.rotary_emb
+        self._inv_freq = rot.inv_freq.detach().to("cpu", torch.float32).clone()
+        self._rope_scaling = float(rot.attention_scaling)
         self.device = weight.device
         self.num_layers = cfg.num_hidden_layers
         self.hidden = cfg.hidden_size
@@ -80,8 +96,14 @@ class HipEngine:
         self._globals = {}
         self._buffers = {}
         with torch.cuda.device(self.device):
-            self._pack_weights()
+            self._pack_weights(model)
             self._allocate(max_ctx, max_prompt)
+
+    @property
+    def model(self):
+        """The borrowed model, or None once the caller dropped it (the engine keeps working: it owns packed
+        copies of the projections and references to the tensors it shares)."""
+        return self._model_ref()
 
     # ------------------------------------------------------------------ weights
     @property
@@ -102,8 +124,7 @@ class HipEngine:
         check(self.lib.lsk_pack_linear(w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), dst.data_ptr(),
                                        tile_offset, tile_stride, rope_hd, self._stream))
 
-    def _pack_weights(self) -> None:
-        m = self.model
+    def _pack_weights(self, m) -> None:
         hd, H, I = self.head_dim, self.hidden, self.intermediate
         qdim, kvdim = self.n_heads * hd, self.n_kv_heads * hd
         for idx, layer in enumerate(m.model.layers):
@@ -144,9 +165,7 @@ class HipEngine:
 
     def _rope_tables(self, length: int):
         """cos/sin exactly as LlamaRotaryEmbedding.forward computes them on CPU (fp32 -> bf16)."""
-        rot = self.model.model.rotary_emb
-        inv_freq = rot.inv_freq.detach().to("cpu", torch.float32)
-        scaling = float(rot.attention_scaling)
+        inv_freq, scaling = self._inv_freq, self._rope_scaling
         pos = torch.arange(length, dtype=torch.float32)
         freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]   # [length, d/2]
         cos = (freqs.cos() * scaling).to(torch.bfloat16)
@@ -160,9 +179,8 @@ class HipEngine:
             self._handle = ctypes.c_void_p(None)
         self.max_ctx = _round_up(max(max_ctx, self.page_size), self.page_size)
         self.max_prompt = max(16, int(max_prompt))
-        rms_eps = float(self.model.config.rms_norm_eps)
         self.cfg = LskConfig(self.num_layers, self.hidden, self.intermediate, self.n_heads, self.n_kv_heads,
-                             self.head_dim, self.vocab, rms_eps, self.max_ctx, self.page_size,
+                             self.head_dim, self.vocab, self.rms_eps, self.max_ctx, self.page_size,
                              self.max_prompt, self.target_wgs)
         ws, kv = ctypes.c_size_t(0), ctypes.c_size_t(0)
         check(self.lib.lsk_workspace_bytes(ctypes.byref(self.cfg), ctypes.byref(ws)))
@@ -224,8 +242,7 @@ class HipEngine:
     def spec_step(self, input_ids: Sequence[int], num_speculations: int, exit_layer: int,
                   eos_token_ids: Sequence[int]) -> StepResult:
         ids = _i32_array(input_ids)
-        eos = [t for t in eos_token_ids if 0 <= t < self.vocab][: _lib.LSK_MAX_EOS]
-        eos_arr = _i32_array(eos)
+        eos, eos_arr = self._eos_array(eos_token_ids)
         res = LskStepResult()
         check(self.lib.lsk_spec_step(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer),
                                      eos_arr, len(eos), ctypes.byref(res), self._stream))
@@ -237,8 +254,7 @@ class HipEngine:
                       eos_token_ids: Sequence[int], max_steps: int):
         """Whole greedy generation in one C-ABI call.  Returns (tokens, matches, drafts, [(T_d, n) per step])."""
         ids = _i32_array(prompt_ids)
-        eos = [t for t in eos_token_ids if 0 <= t < self.vocab][: _lib.LSK_MAX_EOS]
-        eos_arr = _i32_array(eos)
+        eos, eos_arr = self._eos_array(eos_token_ids)
         out = (ctypes.c_int32 * max_steps)()
         sd = (ctypes.c_int32 * max_steps)()
         sm = (ctypes.c_int32 * max_steps)()
@@ -253,8 +269,7 @@ class HipEngine:
                     max_steps: int) -> List[int]:
         """Whole greedy autoregressive generation in one C-ABI call."""
         ids = _i32_array(input_ids)
-        eos = [t for t in eos_token_ids if 0 <= t < self.vocab][: _lib.LSK_MAX_EOS]
-        eos_arr = _i32_array(eos)
+        eos, eos_arr = self._eos_array(eos_token_ids)
         out = (ctypes.c_int32 * max_steps)()
         n_out = ctypes.c_int32(0)
         check(self.lib.lsk_ar_generate(self._handle, ids, len(input_ids), int(layer_end or self.num_layers), eos_arr,

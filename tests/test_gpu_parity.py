@@ -368,3 +368,21 @@ def test_more_than_15_speculations(gpu_device):
     c = spec_s.generate_token_ids(model, prompt, eos, GenerationConfig(max_steps=50, exit_layer=3, num_speculations=6, sample=False))
     assert a.predicted_tokens == b.predicted_tokens == c.predicted_tokens
     assert 0.0 <= a.acceptance_rate <= 1.0
+
+
+def test_engine_is_released_with_its_model(gpu_device):
+    """`get_engine` maps model -> engine weakly and the engine holds no strong reference back: dropping the model
+    frees the engine (packed weights, KV pool) instead of pinning both in HBM."""
+    import gc
+    import weakref
+    from layerskip_amd import engine as engine_mod
+    rec = load_golden("tiny_mha_s0")
+    model = build_case_model(rec).to(gpu_device)
+    eng = engine_mod.get_engine(model, max_ctx=256, max_prompt=64)
+    assert eng.model is model
+    out, _, _, _ = eng.spec_generate(rec["prompt"], rec["num_speculations"], rec["exit_layer"], rec["eos_token_ids"], 8)
+    assert len(out) > 0
+    ref = weakref.ref(eng)
+    del eng, model
+    gc.collect()
+    assert ref() is None

@@ -145,3 +145,15 @@ def test_argument_validation(fake):
     strat = hip_strategies.HipSelfSpeculativeGenerationStrategy()
     with pytest.raises(ValueError):
         strat.generate_token_ids(model, rec["prompt"], rec["eos_token_ids"], _cfg(rec, exit_layer=99))
+
+
+def test_eos_list_is_never_silently_truncated():
+    from layerskip_amd._lib import LSK_MAX_EOS, LskError
+    from layerskip_amd.engine import HipEngine
+    eng = object.__new__(HipEngine)          # no device needed for the host-side list handling
+    eng.vocab = 100
+    eos, arr = eng._eos_array([2, 1000, -1, 7])
+    assert eos == [2, 7] and list(arr)[:2] == [2, 7]         # ids outside the vocabulary can never be produced
+    assert eng._eos_array([])[0] == []
+    with pytest.raises(LskError):
+        eng._eos_array(list(range(LSK_MAX_EOS + 1)))
