@@ -88,7 +88,7 @@ __device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int s
 }
 
 template <int PRO, int MB>
-__device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned char* xs, int xstride, const float* inv,
+__device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned char* xs, int xstride, const float (&sv)[MB],
                                                 int steps_c, int tid, const bf16x8 (&xr)[MB], const bf16x8& nw) {
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
@@ -97,7 +97,7 @@ __device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned ch
             if (i < p.M) {
                 bf16x8 v = xr[i];
                 if (PRO == PRO_RMS) {
-                    const float s = inv[i];
+                    const float s = sv[i];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float xn = rbf(bf2f(v[j]) * s);           // x32 * rsqrt(var + eps) -> model dtype
@@ -117,7 +117,6 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                                               const int* wait_flag, const int wait_target) {
     float* slab = (float*)(smem + LSK_LDS_SLAB);
     float* red = (float*)(smem + LSK_LDS_RED);
-    float* inv = (float*)(smem + LSK_LDS_INV);
     unsigned char* xs = smem + LSK_LDS_X;
 
     const int tid = threadIdx.x;
@@ -182,6 +181,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     bf16x8 xr[MB];
     bf16x8 nw;
     float ss[MB];
+    float sv[MB];                 // per-row 1/rms (PRO_RMS), wave-uniform
     u32x4 ring[LSK_SPW];
     if (WAIT) {
         // rows not produced yet: start the weight stream, then wait for the producers (bounded spin)
@@ -230,15 +230,20 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             if (lane == 0 && i < M) red[i * LSK_WAVES + w] = t;
         }
         __syncthreads();
-        if (tid < M) {
+        // every wave finishes the statistics for itself: lane i adds row i's 8 per-wave partials in wave order and
+        // the 1/rms values are handed to all lanes through v_readlane (wave-uniform, no second barrier / LDS trip)
+        float my_inv = 0.f;
+        if (lane < MB) {
             float t = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < LSK_WAVES; ++ww) t += red[tid * LSK_WAVES + ww];
-            inv[tid] = 1.0f / sqrtf(t / (float)p.K + p.eps);
+            for (int ww = 0; ww < LSK_WAVES; ++ww) t += red[lane * LSK_WAVES + ww];
+            my_inv = 1.0f / sqrtf(t / (float)p.K + p.eps);
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+            sv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_inv), i));
     }
-    lsk_store_chunk<PRO, MB>(p, xs, xstride, inv, cur.steps_c, tid, xr, nw);
+    lsk_store_chunk<PRO, MB>(p, xs, xstride, sv, cur.steps_c, tid, xr, nw);
     if (nchunks > 1) lsk_load_chunk<PRO, MB, WAIT>(p, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);   // prefetch chunk 1
     __syncthreads();
 
@@ -260,7 +265,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
         if (nchunks > 1 && cur.tl == 0 && u > 0) {
             // every wave passed the previous unit's barrier => nobody still reads the old chunk; the rows
             // of this chunk were prefetched into xr one chunk ago, the next chunk's are requested now
-            lsk_store_chunk<PRO, MB>(p, xs, xstride, inv, cur.steps_c, tid, xr, nw);
+            lsk_store_chunk<PRO, MB>(p, xs, xstride, sv, cur.steps_c, tid, xr, nw);
             if (cur.c + 1 < nchunks)
                 lsk_load_chunk<PRO, MB, WAIT>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
             __syncthreads();
