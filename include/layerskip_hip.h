@@ -179,6 +179,9 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
 #define LSK_OPT_FUSED_ATTN 3      /* 1 (default): page partials combined in-launch by the last arriver; 0: second kernel */
 #define LSK_OPT_FLASH_PREFILL 5   /* 1 (default): prompt rows use the flash-shaped prefill attention kernel; 0: 16-row decode passes */
 #define LSK_OPT_FUSED_OPROJ 4     /* 1: attention and o_proj as one role-pipelined launch (rows <= 8); default 0 (measured neutral) */
+#define LSK_OPT_CHAIN 6           /* 1: o_proj -> gate/up -> down [-> next layer's q/k/v] as ONE resident grid with in-launch
+                                     phase hand-offs (lsk_chain.h); default 0: EXPERIMENTAL, compiled but not yet validated on
+                                     hardware (round-2 work); bit-identical by construction when it is */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
 /* Final RMSNorm + lm_head (+ greedy argmax) over rows [row_base, row_base+m)
  * (llama_model_utils.py:204-205, :271-273, :386-387; decode_next_token :120-122).

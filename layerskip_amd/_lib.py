@@ -18,6 +18,7 @@ LSK_OPT_TARGET_WGS = 2
 LSK_OPT_FUSED_ATTN = 3
 LSK_OPT_FUSED_OPROJ = 4
 LSK_OPT_FLASH_PREFILL = 5
+LSK_OPT_CHAIN = 6            # experimental (round 2): chained projection phases in one resident grid
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblayerskip_hip.so")
 

@@ -110,11 +110,24 @@ __device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned ch
     }
 }
 
-// `wait_flag` != nullptr: the activation rows are produced by other workgroups of the SAME launch (role
-// pipelining, lsk_attn_oproj_kernel): fill the weight ring first, then wait until *wait_flag >= wait_target.
-template <int PRO, int EPI, int MB, bool WAIT>
+// One arrival of this workgroup on a phase counter: every wave drains its own (write-through) stores first.
+__device__ __forceinline__ void lsk_phase_arrive(int* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// WAIT: the activation rows (and, for EPI_RESID, the residual rows) are produced by other workgroups of the SAME
+// launch (role pipelining in lsk_attn_oproj_kernel, phase chaining in lsk_chain_kernel): fill the weight ring first,
+// then wait until *wait_flag >= wait_target, then read them with agent-scope loads.
+// PUBLISH: the rows this projection writes (EPI_RESID: h, EPI_SWIGLU: act) are consumed by a later phase of the same
+// launch: write-through (agent-scope) stores, drained by every wave, then ONE arrival ticket per workgroup on
+// `signal_ctr`.
+// RESID_LATE: the residual rows of EPI_RESID are themselves produced in this launch (lsk_chain_kernel's down phase):
+// they are read after the wait, with agent-scope loads, instead of up front.
+template <int PRO, int EPI, int MB, bool WAIT, bool PUBLISH = false, bool RESID_LATE = false>
 __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int block_id, unsigned char* smem,
-                                              const int* wait_flag, const int wait_target) {
+                                              const int* wait_flag, const int wait_target, int* signal_ctr = nullptr) {
     float* slab = (float*)(smem + LSK_LDS_SLAB);
     float* red = (float*)(smem + LSK_LDS_RED);
     unsigned char* xs = smem + LSK_LDS_X;
@@ -143,7 +156,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     float pre_b[4] = {0.f, 0.f, 0.f, 0.f};      // QKV: sin
     int pre_pg[4] = {0, 0, 0, 0};               // QKV: KV page of each row's position
     int base_pos = 0;
-    if (EPI == EPI_RESID) {
+    if (EPI == EPI_RESID && !RESID_LATE) {
         if (is_owner) {
             const int n = (tile0 + w) * 16 + c16;
 #pragma unroll
@@ -198,6 +211,19 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             }
         }
         __syncthreads();
+        if (EPI == EPI_RESID && RESID_LATE && is_owner) {
+            // the residual rows were written by an earlier phase of this launch: agent-scope loads
+            const int n = (tile0 + w) * 16 + c16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rg * 4 + i;
+                if (row < M && n < p.N) {
+                    const unsigned short bits = __hip_atomic_load((const unsigned short*)(p.h + (size_t)row * p.ldh + n),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pre_a[i] = bf2f(__builtin_bit_cast(bf16_t, bits));
+                }
+            }
+        }
     }
     if (PRO == PRO_RMS) {
 #pragma unroll
@@ -313,8 +339,12 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
-                if (row < M && n < p.N)
-                    p.h[(size_t)row * p.ldh + n] = f2bf(pre_a[i] + rbf(own0[i]));   // residual + Linear(...) in model dtype
+                if (row < M && n < p.N) {
+                    const bf16_t r = f2bf(pre_a[i] + rbf(own0[i]));                 // residual + Linear(...) in model dtype
+                    if (PUBLISH) __hip_atomic_store((unsigned short*)(p.h + (size_t)row * p.ldh + n), __builtin_bit_cast(unsigned short, r),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+                    else p.h[(size_t)row * p.ldh + n] = r;
+                }
             }
         }
     } else if (EPI == EPI_SWIGLU) {
@@ -327,7 +357,10 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                     const float g = rbf(own0[i]);                    // gate_proj(x)
                     const float uu = rbf(own1[i]);                   // up_proj(x)
                     const float s = rbf(g / (1.0f + expf(-g)));      // silu in fp32, one rounding
-                    p.act[(size_t)row * p.ldact + n] = f2bf(s * uu);
+                    const bf16_t r = f2bf(s * uu);
+                    if (PUBLISH) __hip_atomic_store((unsigned short*)(p.act + (size_t)row * p.ldact + n), __builtin_bit_cast(unsigned short, r),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+                    else p.act[(size_t)row * p.ldact + n] = r;
                 }
             }
         }
@@ -408,6 +441,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             p.part_idx[block_id * 16 + tid] = idx;
         }
     }
+    if (PUBLISH) lsk_phase_arrive(signal_ctr);
 }
 
 template <int PRO, int EPI, int MB>
