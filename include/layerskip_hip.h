@@ -180,9 +180,33 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
 #define LSK_OPT_FLASH_PREFILL 5   /* 1 (default): prompt rows use the flash-shaped prefill attention kernel; 0: 16-row decode passes */
 #define LSK_OPT_FUSED_OPROJ 4     /* 1: attention and o_proj as one role-pipelined launch (rows <= 8); default 0 (measured neutral) */
 #define LSK_OPT_CHAIN 6           /* 1: o_proj -> gate/up -> down [-> next layer's q/k/v] as ONE resident grid with in-launch
-                                     phase hand-offs (lsk_chain.h); default 0: EXPERIMENTAL, compiled but not yet validated on
-                                     hardware (round-2 work); bit-identical by construction when it is */
+                                     phase hand-offs (lsk_chain.h); bit-identical; default 0 (measured slower than launch
+                                     boundaries: DESIGN.md 3.3) */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
+/* ---- sampling on the device (sample=True; GenerationConfig temperature / top_k / top_p, generator_base.py:35-44) ----
+ * EXPERIMENTAL in round 1: compiled and exported, exercised only by the opt-in tests (LSK_EXPERIMENTAL=1); the strategies'
+ * default sampling path still materialises the logits for the host (hip_strategies.py).
+ * Random numbers: Philox4x32-10, key = seed, counter = (element / 4, tag, offset); `offset` must differ between calls
+ * that are to be independent (the strategies pass a step counter). */
+/* bytes of device scratch lsk_spec_step_sampled needs (logits + draft / verify probability rows, fp32) */
+int lsk_sampling_scratch_bytes(const lsk_config* cfg, size_t* out_bytes);
+/* decode_next_token(sample=True) (llama_model_utils.py:123-131) over m rows of device logits ([m][ld] fp32):
+ * logits / temperature -> top-k -> top-p -> softmax -> one categorical draw per row.  tokens_out: DEVICE int32[m];
+ * probs_out: DEVICE fp32 [m][ld], the warped distribution's probabilities (what the reference returns next to the token). */
+int lsk_sample_rows(lsk_engine* e, const void* logits, int32_t ld, int32_t m, float temperature, int32_t top_k,
+                    float top_p, uint64_t seed, uint64_t offset, int32_t tag0, int32_t* tokens_out, void* probs_out,
+                    void* stream);
+/* single_step_speculation with sample=True (self_speculation_generator.py:101-229): lsk_spec_step with every argmax
+ * replaced by a draw and the prefix match replaced by modified rejection sampling (SSG:191-199, max_fn :27-29). */
+int lsk_spec_step_sampled(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t num_speculations,
+                          int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, float temperature,
+                          int32_t top_k, float top_p, uint64_t seed, uint64_t offset, void* scratch,
+                          size_t scratch_bytes, lsk_step_result* out, void* stream);
+/* the rejection-sampling kernel alone (tests): all pointers DEVICE; draft[-1] must be addressable; result int32[64] */
+int lsk_test_accept_sampled(int32_t* draft, int32_t* verified, int32_t num_drafts, const int32_t* eos, int32_t n_eos,
+                            const void* p_draft, const void* p_verify, int32_t ld, int32_t vocab, uint64_t seed,
+                            uint64_t offset, int32_t* result, void* stream);
+
 /* Final RMSNorm + lm_head (+ greedy argmax) over rows [row_base, row_base+m)
  * (llama_model_utils.py:204-205, :271-273, :386-387; decode_next_token :120-122).
  * logits_out: optional device fp32 [m][ld_logits] (values are bf16-rounded like the model dtype);

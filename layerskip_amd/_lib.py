@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_uint64, c_void_p
 
 LSK_MAX_ROWS = 16
 LSK_MAX_SPEC = 15
@@ -18,7 +18,7 @@ LSK_OPT_TARGET_WGS = 2
 LSK_OPT_FUSED_ATTN = 3
 LSK_OPT_FUSED_OPROJ = 4
 LSK_OPT_FLASH_PREFILL = 5
-LSK_OPT_CHAIN = 6            # experimental (round 2): chained projection phases in one resident grid
+LSK_OPT_CHAIN = 6            # chained projection phases in one resident grid (bit-identical, measured slower; default off)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblayerskip_hip.so")
 
@@ -70,6 +70,13 @@ PROTOTYPES = {
     "lsk_run_bulk": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "lsk_engine_set_option": (c_int32, [c_void_p, c_int32, c_int32]),
     "lsk_run_head": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, POINTER(c_int32), c_void_p]),
+    "lsk_sampling_scratch_bytes": (c_int32, [POINTER(LskConfig), POINTER(c_size_t)]),
+    "lsk_sample_rows": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_int32, c_float, c_uint64, c_uint64, c_int32,
+                                  c_void_p, c_void_p, c_void_p]),
+    "lsk_spec_step_sampled": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, POINTER(c_int32), c_int32, c_float,
+                                        c_int32, c_float, c_uint64, c_uint64, c_void_p, c_size_t, POINTER(LskStepResult), c_void_p]),
+    "lsk_test_accept_sampled": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                          c_uint64, c_uint64, c_void_p, c_void_p]),
     "lsk_read_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "lsk_write_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "lsk_test_gemm": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_int32, c_void_p]),

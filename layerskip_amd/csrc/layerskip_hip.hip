@@ -171,6 +171,8 @@ __global__ void lsk_accept_kernel(int* __restrict__ draft, const int* __restrict
     }
 }
 
+#include "lsk_sample.h"      // needs the LSK_RES_* result-block layout above
+
 __global__ void lsk_set_state_kernel(StepState* st, int kv_len, int add) {
     if (add) st->kv_len += kv_len; else st->kv_len = kv_len;
 }
@@ -1216,6 +1218,138 @@ extern "C" int lsk_write_rows(lsk_engine* e, int32_t buffer, int32_t row_base, i
     const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
     if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base + m > cap) return lsk_fail("lsk_write_rows: rows out of range");
     HIP_OK(hipMemcpyAsync(buf_rows(e, buffer, row_base), src, (size_t)m * e->cfg.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- sampling on the device (lsk_sample.h) --------------------------------------------------
+static int sampling_ld(const lsk_config& c) { return (c.vocab + 3) / 4 * 4; }
+
+extern "C" int lsk_sampling_scratch_bytes(const lsk_config* cfg, size_t* out_bytes) {
+    LSK_TRY(check_cfg(cfg));
+    if (!out_bytes) return lsk_fail("null out");
+    // logits [17][ld] | draft probabilities [16][ld] | verify probabilities [17][ld], fp32
+    *out_bytes = (size_t)(2 * (LSK_MAX_ROWS + 1) + LSK_MAX_ROWS) * sampling_ld(*cfg) * sizeof(float);
+    return 0;
+}
+
+static int check_sampling_args(float temperature, float top_p) {
+    if (!(temperature > 0.f)) return lsk_fail("temperature %g must be > 0", (double)temperature);
+    if (!(top_p >= 0.f)) return lsk_fail("top_p %g must be >= 0", (double)top_p);
+    return 0;
+}
+
+static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, float temperature, int top_k, float top_p, uint64_t seed,
+                         uint64_t offset, int tag0, int* tokens_dev, float* probs, bf16_t* embed_dst, hipStream_t st) {
+    SampleParams sp{};
+    sp.logits = logits; sp.ld = ld; sp.vocab = e->cfg.vocab; sp.inv_temperature = 1.0f / temperature;
+    sp.top_k = top_k; sp.top_p = top_p;
+    sp.seed_lo = (unsigned int)seed; sp.seed_hi = (unsigned int)(seed >> 32);
+    sp.off_lo = (unsigned int)offset; sp.off_hi = (unsigned int)(offset >> 32);
+    sp.tag0 = tag0; sp.tokens_out = tokens_dev; sp.probs_out = probs;
+    sp.embed = e->embed; sp.hidden = e->cfg.hidden; sp.embed_dst = embed_dst;
+    hipLaunchKernelGGL(lsk_sample_kernel, dim3(m), dim3(LSK_SAMPLE_THREADS), 0, st, sp);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// RNG tags inside one step (Philox counter word 1): draft row j -> j, verify row r -> 32 + r, acceptance uniforms -> 64,
+// residual draw -> 96.  `offset` (counter words 2-3) must differ between steps: the caller passes a step counter.
+#define LSK_TAG_VERIFY 32
+#define LSK_TAG_ACCEPT 64
+#define LSK_TAG_RESIDUAL 96
+
+extern "C" int lsk_sample_rows(lsk_engine* e, const void* logits, int32_t ld, int32_t m, float temperature, int32_t top_k, float top_p,
+                               uint64_t seed, uint64_t offset, int32_t tag0, int32_t* tokens_out, void* probs_out, void* stream) {
+    LSK_TRY(ready(e));
+    if (!logits || !tokens_out || !probs_out) return lsk_fail("lsk_sample_rows: null pointer");
+    if (m < 1 || m > LSK_MAX_ROWS + 1 || ld < e->cfg.vocab) return lsk_fail("lsk_sample_rows: m=%d ld=%d out of range", m, ld);
+    LSK_TRY(check_sampling_args(temperature, top_p));
+    return launch_sample(e, (const float*)logits, ld, m, temperature, top_k, top_p, seed, offset, tag0, tokens_out, (float*)probs_out, nullptr,
+                         (hipStream_t)stream);
+}
+
+extern "C" int lsk_test_accept_sampled(int32_t* draft, int32_t* verified, int32_t num_drafts, const int32_t* eos, int32_t n_eos,
+                                       const void* p_draft, const void* p_verify, int32_t ld, int32_t vocab, uint64_t seed, uint64_t offset,
+                                       int32_t* result, void* stream) {
+    if (!draft || !verified || !p_draft || !p_verify || !result) return lsk_fail("lsk_test_accept_sampled: null pointer");
+    if (num_drafts < 0 || num_drafts > LSK_MAX_SPEC || vocab < 1 || ld < vocab) return lsk_fail("lsk_test_accept_sampled: bad arguments");
+    AcceptSampledParams ap{};
+    ap.draft = draft; ap.verified = verified; ap.num_drafts = num_drafts; ap.eos = eos; ap.n_eos = n_eos; ap.prompt_len = 1;
+    ap.p_draft = (const float*)p_draft; ap.p_verify = (const float*)p_verify; ap.ld = ld; ap.vocab = vocab;
+    ap.seed_lo = (unsigned int)seed; ap.seed_hi = (unsigned int)(seed >> 32);
+    ap.off_lo = (unsigned int)offset; ap.off_hi = (unsigned int)(offset >> 32);
+    ap.tag_accept = LSK_TAG_ACCEPT; ap.tag_residual = LSK_TAG_RESIDUAL; ap.st = nullptr; ap.result = result;
+    hipLaunchKernelGGL(lsk_accept_sampled_kernel, dim3(1), dim3(LSK_SAMPLE_THREADS), 0, (hipStream_t)stream, ap);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// single_step_speculation with sample=True (self_speculation_generator.py:101-229, decode_next_token
+// llama_model_utils.py:109-131): the step of lsk_spec_step with every argmax replaced by a draw from the warped
+// distribution and the greedy prefix match replaced by modified rejection sampling -- all on the device.
+extern "C" int lsk_spec_step_sampled(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t num_speculations,
+                                     int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, float temperature, int32_t top_k,
+                                     float top_p, uint64_t seed, uint64_t offset, void* scratch, size_t scratch_bytes,
+                                     lsk_step_result* out, void* stream) {
+    LSK_TRY(ready(e));
+    hipStream_t st = (hipStream_t)stream;
+    const lsk_config& c = e->cfg;
+    const int P = prompt_len, S = num_speculations, E = exit_layer, L = c.num_layers;
+    if (!input_ids || !out || !scratch) return lsk_fail("lsk_spec_step_sampled: null pointer");
+    LSK_TRY(validate_step_args(e, P, S, E, eos_token_ids, n_eos));
+    LSK_TRY(check_sampling_args(temperature, top_p));
+    size_t need = 0;
+    LSK_TRY(lsk_sampling_scratch_bytes(&c, &need));
+    if (scratch_bytes < need) return lsk_fail("sampling scratch too small: %zu < %zu", scratch_bytes, need);
+    if (e->kv_len_host + P + S > c.max_ctx) return lsk_fail("context overflow: %d + %d + %d > max_ctx %d", e->kv_len_host, P, S, c.max_ctx);
+    const int ld = sampling_ld(c);
+    float* logits = (float*)scratch;
+    float* p_draft = logits + (size_t)(LSK_MAX_ROWS + 1) * ld;
+    float* p_verify = p_draft + (size_t)LSK_MAX_ROWS * ld;
+    LSK_TRY(upload_step_inputs(e, input_ids, P, eos_token_ids, n_eos, st));
+    const int* kvp = &e->state->kv_len;
+    if (P > 1) {
+        LSK_TRY(embed_rows_dev(e, e->bulk_ids, P - 1, e->hbulk, st));
+        LSK_TRY(run_bulk(e, P - 1, kvp, 0, E, st));
+    }
+    int* greedy_scratch = e->verified;      // the head kernel's argmax lands here and is ignored
+    for (int j = 0; j <= S; ++j) {
+        bf16_t* xr = e->hrow + (size_t)j * c.hidden;
+        if (j == 0) LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, xr, st));
+        LSK_TRY(run_layers(e, xr, 1, kvp, P - 1 + j, 0, E, st));
+        if (j < S) {
+            LSK_TRY(run_head(e, xr, 1, logits, ld, greedy_scratch, st));
+            LSK_TRY(launch_sample(e, logits, ld, 1, temperature, top_k, top_p, seed, offset, j, e->row_tokens + j + 1,
+                                  p_draft + (size_t)j * ld, xr + c.hidden, st));
+        }
+    }
+    if (P > 1) LSK_TRY(run_bulk(e, P - 1, kvp, E, L, st));
+    LSK_TRY(run_layers(e, e->hrow, S + 1, kvp, P - 1, E, L, st));
+    LSK_TRY(run_head(e, e->hrow, S + 1, logits, ld, greedy_scratch, st));
+    LSK_TRY(launch_sample(e, logits, ld, S + 1, temperature, top_k, top_p, seed, offset, LSK_TAG_VERIFY, e->verified, p_verify, nullptr, st));
+    AcceptSampledParams ap{};
+    ap.draft = e->row_tokens + 1; ap.verified = e->verified; ap.num_drafts = S; ap.eos = e->eos; ap.n_eos = n_eos; ap.prompt_len = P;
+    ap.p_draft = p_draft; ap.p_verify = p_verify; ap.ld = ld; ap.vocab = c.vocab;
+    ap.seed_lo = (unsigned int)seed; ap.seed_hi = (unsigned int)(seed >> 32);
+    ap.off_lo = (unsigned int)offset; ap.off_hi = (unsigned int)(offset >> 32);
+    ap.tag_accept = LSK_TAG_ACCEPT; ap.tag_residual = LSK_TAG_RESIDUAL; ap.st = e->state; ap.result = e->result;
+    hipLaunchKernelGGL(lsk_accept_sampled_kernel, dim3(1), dim3(LSK_SAMPLE_THREADS), 0, st, ap);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(e->host_result, e->result, sizeof(int) * LSK_RES_INTS, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipEventRecord(e->step_done[0], st));
+    HIP_OK(hipEventSynchronize(e->step_done[0]));
+    const int* host_res = e->host_result;
+    memset(out, 0, sizeof(*out));
+    out->num_matches = host_res[0];
+    out->num_drafts = host_res[1];
+    out->num_emitted = host_res[0] + 1;
+    out->next_token = host_res[2];
+    out->kv_len = host_res[3];
+    for (int i = 0; i <= host_res[0]; ++i) out->emitted[i] = host_res[LSK_RES_EMIT + i];
+    for (int i = 0; i < S; ++i) out->draft_tokens[i] = host_res[LSK_RES_DRAFT + i];
+    for (int i = 0; i <= S; ++i) out->verified_tokens[i] = host_res[LSK_RES_VERIFIED + i];
+    e->next_token_host = host_res[2];
+    e->kv_len_host = host_res[3];
     return 0;
 }
 

@@ -185,6 +185,7 @@ class HipEngine:
         ws, kv = ctypes.c_size_t(0), ctypes.c_size_t(0)
         check(self.lib.lsk_workspace_bytes(ctypes.byref(self.cfg), ctypes.byref(ws)))
         check(self.lib.lsk_kv_pool_bytes(ctypes.byref(self.cfg), ctypes.byref(kv)))
+        self._buffers.pop("sampling", None)
         self._buffers["ws"] = torch.zeros(ws.value, dtype=torch.uint8, device=self.device)
         self._buffers["kv"] = torch.zeros(kv.value, dtype=torch.uint8, device=self.device)
         cos, sin = self._rope_tables(self.max_ctx)
@@ -264,6 +265,46 @@ class HipEngine:
                                          sd, sm, ctypes.byref(ns), self._stream))
         steps = [(sd[i], sm[i]) for i in range(ns.value)]
         return list(out[: n_out.value]), tm.value, td.value, steps
+
+    # ------------------------------------------------------------------ sampling on the device (opt-in)
+    def _sampling_scratch(self) -> torch.Tensor:
+        buf = self._buffers.get("sampling")
+        if buf is None:
+            n = ctypes.c_size_t(0)
+            check(self.lib.lsk_sampling_scratch_bytes(ctypes.byref(self.cfg), ctypes.byref(n)))
+            buf = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+            self._buffers["sampling"] = buf
+        return buf
+
+    def sample_rows(self, logits: torch.Tensor, temperature: float, top_k: int, top_p: float, seed: int, offset: int,
+                    tag0: int = 0):
+        """decode_next_token(sample=True) over rows of device logits [m, ld] (fp32).  Returns (tokens int32[m] on
+        the device, probabilities fp32 [m, ld])."""
+        if logits.dtype != torch.float32 or logits.device != self.device or logits.dim() != 2 or logits.stride(1) != 1:
+            raise _lib.LskError("logits must be a [m, ld] fp32 tensor on the engine device")
+        m, ld = logits.shape[0], logits.stride(0)
+        toks = torch.empty(m, dtype=torch.int32, device=self.device)
+        probs = torch.empty(m, ld, dtype=torch.float32, device=self.device)
+        check(self.lib.lsk_sample_rows(self._handle, logits.data_ptr(), ld, m, float(temperature), int(top_k), float(top_p),
+                                       int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(tag0), toks.data_ptr(),
+                                       probs.data_ptr(), self._stream))
+        return toks, probs
+
+    def spec_step_sampled(self, input_ids: Sequence[int], num_speculations: int, exit_layer: int,
+                          eos_token_ids: Sequence[int], temperature: float, top_k: int, top_p: float, seed: int,
+                          offset: int) -> StepResult:
+        """single_step_speculation with sample=True, entirely on the device (lsk_spec_step_sampled)."""
+        ids = _i32_array(input_ids)
+        eos, eos_arr = self._eos_array(eos_token_ids)
+        res = LskStepResult()
+        scratch = self._sampling_scratch()
+        check(self.lib.lsk_spec_step_sampled(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer), eos_arr,
+                                             len(eos), float(temperature), int(top_k), float(top_p), int(seed) & (2 ** 64 - 1),
+                                             int(offset) & (2 ** 64 - 1), scratch.data_ptr(), scratch.numel(), ctypes.byref(res),
+                                             self._stream))
+        n, s = res.num_matches, int(num_speculations)
+        return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
+                          list(res.draft_tokens[:s]), list(res.verified_tokens[: s + 1]))
 
     def ar_generate(self, input_ids: Sequence[int], layer_end: Optional[int], eos_token_ids: Sequence[int],
                     max_steps: int) -> List[int]:

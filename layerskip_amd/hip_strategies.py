@@ -78,8 +78,13 @@ def _residual_distribution(p_verify: torch.Tensor, p_draft: torch.Tensor, eps: f
 
 
 class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
-    def __init__(self, engine_kwargs: Optional[dict] = None, fused_generate: bool = True) -> None:
+    def __init__(self, engine_kwargs: Optional[dict] = None, fused_generate: bool = True, device_sampling: bool = False) -> None:
         self.engine_kwargs = engine_kwargs or {}
+        # device_sampling (opt-in, experimental in round 1): `sample=True` steps without logits processors run on the
+        # device (lsk_spec_step_sampled: top-k / top-p thresholds, Gumbel-max draws, rejection sampling) instead of
+        # materialising the logits for torch.  Seeded from torch.initial_seed(); one Philox offset per step.
+        self.device_sampling = device_sampling
+        self._sample_offset = 0
         # fused_generate: greedy generations without processors / criteria / streamer run as ONE C-ABI call
         # (lsk_spec_generate: the loop of SSG:51-95 with the steps pipelined on the stream)
         self.fused_generate = fused_generate
@@ -149,7 +154,12 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         if not (1 <= exit_layer < engine.num_layers):
             raise ValueError(f"exit_layer={exit_layer} must be in [1, {engine.num_layers})")
         new_ids = [int(t) for t in input_ids[0].tolist()]
-        if sample or logits_processors or spec > _lib.LSK_MAX_SPEC:
+        if (sample and self.device_sampling and not logits_processors and spec <= _lib.LSK_MAX_SPEC
+                and hasattr(engine, "spec_step_sampled")):
+            self._sample_offset += 1
+            step = engine.spec_step_sampled(new_ids, spec, exit_layer, eos_token_ids, temperature, top_k, top_p,
+                                            torch.initial_seed(), self._sample_offset)
+        elif sample or logits_processors or spec > _lib.LSK_MAX_SPEC:
             # (more than 15 speculations do not fit the 16-row fused verify block: same kernels, rows walked in
             #  16-row passes from the host)
             step = self._slow_step(engine, new_ids, spec, exit_layer, eos_token_ids, sample, temperature, top_k, top_p,

@@ -97,3 +97,106 @@ def emitted_distribution(p_draft_row: np.ndarray, p_verify_row: np.ndarray) -> n
     keep = np.minimum(p, q)                                   # P(draw x and keep it)
     reject_mass = 1.0 - keep.sum()
     return keep + reject_mass * residual(p_verify_row, p_draft_row).astype(np.float64)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Model of the DEVICE algorithm (layerskip_amd/csrc/lsk_sample.h), draw for draw: same Philox4x32-10 stream, same
+# 16-bit key thresholds, same Gumbel-max draws.  The kernels are checked against this; this is checked against the
+# reference-pinned functions above (kept sets, probabilities) and against the closed-form distributions.
+# ----------------------------------------------------------------------------------------------------------------
+TAG_VERIFY, TAG_ACCEPT, TAG_RESIDUAL = 32, 64, 96
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 (Salmon et al., SC'11; the Random123 known-answer vectors are in the tests)."""
+    c = [np.asarray(v, dtype=np.uint64) & _M32 for v in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0) & _M32, np.uint64(k1) & _M32
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & _M32, p1 & _M32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & _M32, p0 & _M32]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & _M32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & _M32
+    return [v.astype(np.uint32) for v in c]
+
+
+def u01(bits: np.ndarray) -> np.ndarray:
+    return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+
+
+def device_uniforms(n: int, tag: int, seed: int, offset: int) -> np.ndarray:
+    """u_i of element i (counter = (i // 4, tag, offset), word i % 4)."""
+    groups = (n + 3) // 4
+    words = philox4x32_10(np.arange(groups), tag, offset & 0xFFFFFFFF, offset >> 32, seed & 0xFFFFFFFF, seed >> 32)
+    return u01(np.stack(words, axis=1).reshape(-1)[:n])
+
+
+def key16(x: np.ndarray) -> np.ndarray:
+    b = x.astype(np.float32).view(np.uint32)
+    k = (b >> np.uint32(16)).astype(np.int64)
+    return np.where(b & np.uint32(0x80000000), (~k) & 0xFFFF, k | 0x8000)
+
+
+def device_warp(logits: np.ndarray, temperature: float, top_k: int, top_p: float):
+    """(kept mask, probabilities) exactly as lsk_sample_kernel computes them (thresholds in the 16-bit key space)."""
+    x = logits.astype(np.float32)
+    v = x.shape[0]
+    keys = key16(x)
+    m = x.max()
+    e = np.exp(((x - m) * np.float32(1.0 / temperature)).astype(np.float32)).astype(np.float32)
+    K = 0
+    if 0 < top_k < v:
+        K = int(np.sort(keys)[-top_k])                       # largest key with count{key >= K} >= k
+    P = K
+    if top_p < 1.0:
+        if not top_p > 0.0:
+            P = int(keys.max())
+        else:
+            z = e[keys >= K].sum(dtype=np.float32)
+            budget = np.float32(top_p) * z
+            cand = np.unique(keys[keys >= K])
+            P = int(keys.max())
+            for c in cand:                                   # smallest key with mass{key > c} < budget
+                if e[keys > c].sum(dtype=np.float32) < budget:
+                    P = int(c)
+                    break
+    keep = keys >= P
+    probs = np.where(keep, e, np.float32(0.0)).astype(np.float32)
+    return keep, (probs / probs.sum(dtype=np.float32)).astype(np.float32)
+
+
+def device_sample_row(logits: np.ndarray, temperature: float, top_k: int, top_p: float, seed: int, offset: int, tag: int):
+    """(token, probabilities) of one row: Gumbel-max over the kept set with the device's random stream."""
+    keep, probs = device_warp(logits, temperature, top_k, top_p)
+    x = logits.astype(np.float32)
+    z = ((x - x.max()) * np.float32(1.0 / temperature)).astype(np.float32)
+    u = device_uniforms(x.shape[0], tag, seed, offset)
+    g = -np.log(-np.log(u.astype(np.float64)))
+    score = np.where(keep, z.astype(np.float64) + g, -np.inf)
+    return int(np.argmax(score)), probs
+
+
+def device_accept(draft_tokens: Sequence[int], verified_tokens: Sequence[int], p_draft: Sequence[np.ndarray],
+                  p_verify: Sequence[np.ndarray], eos: Sequence[int], seed: int, offset: int) -> Tuple[int, int, int]:
+    """(num_matches, num_drafts, emitted token) as lsk_accept_sampled_kernel decides them."""
+    td = len(draft_tokens)
+    for i, t in enumerate(draft_tokens):
+        if t in eos:
+            td = i + 1
+            break
+    u = u01(philox4x32_10(np.arange(max(td, 1)), TAG_ACCEPT, offset & 0xFFFFFFFF, offset >> 32, seed & 0xFFFFFFFF, seed >> 32)[0])
+    n = 0
+    for i in range(td):
+        tok = draft_tokens[i]
+        if u[i] < min(np.float32(1.0), np.float32(p_verify[i][tok]) / np.float32(p_draft[i][tok])):
+            n += 1
+        else:
+            break
+    if n == td:
+        return n, td, int(verified_tokens[td])
+    w = p_verify[n].astype(np.float32) - p_draft[n].astype(np.float32)
+    uu = device_uniforms(w.shape[0], TAG_RESIDUAL, seed, offset)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        score = np.where(w > 0, np.log(np.where(w > 0, w, 1.0).astype(np.float64)) - np.log(-np.log(uu.astype(np.float64))), -np.inf)
+    return n, td, int(np.argmax(score))

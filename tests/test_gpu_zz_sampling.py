@@ -1,0 +1,108 @@
+"""Device-side sampling (lsk_sample.h) against the draw-for-draw model in oracle/sampling_oracle.py.
+OPT-IN: the kernels were written at the end of round 1 after the GPU budget was spent, so these checks only run
+with LSK_EXPERIMENTAL=1 until they have been seen green on hardware (then the guard goes away and
+`device_sampling` can become the strategies' default for sample=True)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, build_case_model, load_golden
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("LSK_EXPERIMENTAL") != "1", reason="opt-in: set LSK_EXPERIMENTAL=1")]
+
+CASES = json.load(open(os.path.join(GOLDEN_DIR, "sampling", "cases.json")))
+SHAPE_OF_VOCAB = {512: "tiny-mha", 1000: "tiny-gqa", 768: "tiny-d64"}
+
+
+def _engine(vocab, gpu_device):
+    from layerskip_amd import synthetic
+    from layerskip_amd.engine import HipEngine
+    shape = SHAPE_OF_VOCAB[vocab]
+    cfg = synthetic.make_config(shape)
+    model = synthetic.build_model(cfg, seed=0, exit_layer=synthetic.default_exit_layer(shape), late_damping=0.1).to(gpu_device)
+    return model, HipEngine(model, max_ctx=512, max_prompt=64)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_sample_rows_matches_the_model_draw_for_draw(gpu_device, idx):
+    from oracle import sampling_oracle as so
+    rec = CASES[idx]
+    model, eng = _engine(rec["vocab"], gpu_device)
+    rows = np.stack([np.asarray(rec["draft_logits"], dtype=np.float32), np.asarray(rec["verify_logits"], dtype=np.float32)])
+    logits = torch.tensor(rows, device=gpu_device)
+    mismatches = total = 0
+    for offset in range(40):
+        toks, probs = eng.sample_rows(logits, rec["temperature"], rec["top_k"], rec["top_p"], seed=4242, offset=offset, tag0=5)
+        toks, probs = toks.cpu().tolist(), probs.cpu().numpy()
+        for r in range(2):
+            want_tok, want_probs = so.device_sample_row(rows[r], rec["temperature"], rec["top_k"], rec["top_p"], 4242, offset, 5 + r)
+            assert ((probs[r] > 0) == (want_probs > 0)).all()
+            assert np.allclose(probs[r], want_probs, rtol=0, atol=2e-6)
+            assert want_probs[toks[r]] > 0
+            total += 1
+            mismatches += int(toks[r] != want_tok)      # fast-math log/exp can flip a near-tie of two Gumbel scores
+    assert mismatches <= max(1, total // 25), (mismatches, total)
+    eng.close()
+
+
+def test_accept_sampled_kernel_matches_the_model(gpu_device):
+    from layerskip_amd import _lib
+    from oracle import sampling_oracle as so
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    v, ld = 640, 640
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for trial in range(60):
+        td = int(rng.integers(0, 7))
+        pd = [so.probabilities(rng.normal(size=v).astype(np.float32) * 2) for _ in range(max(td, 1))]
+        pv = [so.probabilities(rng.normal(size=v).astype(np.float32) * 2) for _ in range(td + 1)]
+        drafts = [int(rng.choice(v, p=p.astype(np.float64) / p.astype(np.float64).sum())) for p in pd[:td]]
+        verified = [int(np.argmax(p)) for p in pv]
+        eos = [drafts[1]] if (td >= 3 and trial % 5 == 0) else []
+        d_dev = torch.tensor([-1] + drafts + [0] * (17 - td), dtype=torch.int32, device=gpu_device)
+        v_dev = torch.tensor(verified + [0] * (17 - len(verified)), dtype=torch.int32, device=gpu_device)
+        e_dev = torch.tensor(eos + [0] * (8 - len(eos)), dtype=torch.int32, device=gpu_device)
+        pd_dev = torch.tensor(np.stack(pd), device=gpu_device)
+        pv_dev = torch.tensor(np.stack(pv), device=gpu_device)
+        res = torch.zeros(64, dtype=torch.int32, device=gpu_device)
+        _lib.check(lib.lsk_test_accept_sampled(d_dev.data_ptr() + 4, v_dev.data_ptr(), td, e_dev.data_ptr(), len(eos), pd_dev.data_ptr(),
+                                               pv_dev.data_ptr(), ld, v, 77, trial, res.data_ptr(), st))
+        torch.cuda.synchronize()
+        r = res.cpu().tolist()
+        n, ntd, tok = so.device_accept(drafts, verified, pd, pv, eos, seed=77, offset=trial)
+        assert (r[0], r[1]) == (n, ntd), (trial, r[:4], n, ntd)
+        if n == ntd:
+            assert r[2] == tok
+        else:
+            assert pv[n][r[2]] > pd[n][r[2]]
+        assert r[4:4 + n] == drafts[:n] and r[4 + n] == r[2]
+
+
+def test_device_sampled_generation_matches_the_host_path_in_distribution(gpu_device):
+    from layerskip_amd import GenerationConfig
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    rec = load_golden("tiny_mha_s1")
+    model = build_case_model(rec).to(gpu_device)
+    kw = dict(max_steps=10, exit_layer=rec["exit_layer"], num_speculations=4, sample=True, temperature=0.12, top_k=0, top_p=0.9)
+    host, dev = HipSelfSpeculativeGenerationStrategy(), HipSelfSpeculativeGenerationStrategy(device_sampling=True)
+    acc = {"host": [], "dev": []}
+    first = {"host": {}, "dev": {}}
+    n_runs = 120
+    for i in range(n_runs):
+        for name, strat in (("host", host), ("dev", dev)):
+            torch.manual_seed(100 + i)
+            r = strat.generate_token_ids(model, list(rec["prompt"]), list(rec["eos_token_ids"]), GenerationConfig(**kw))
+            assert 0 < len(r.predicted_tokens) <= 10
+            acc[name].append(r.acceptance_rate)
+            first[name][r.predicted_tokens[0]] = first[name].get(r.predicted_tokens[0], 0) + 1
+    ma, mb = np.mean(acc["host"]), np.mean(acc["dev"])
+    sd = np.std(acc["host"])
+    assert abs(ma - mb) < 4 * sd * (2 / n_runs) ** 0.5 + 0.01, (ma, mb, sd)
+    keys = set(first["host"]) | set(first["dev"])
+    tv = 0.5 * sum(abs(first["host"].get(k, 0) - first["dev"].get(k, 0)) / n_runs for k in keys)
+    assert tv < 0.25, tv

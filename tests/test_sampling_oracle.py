@@ -85,3 +85,79 @@ def test_inverse_cdf_is_a_categorical_draw():
     us = (np.arange(20000) + 0.5) / 20000
     counts = np.bincount([so.inverse_cdf(p, u) for u in us], minlength=5) / 20000
     assert np.abs(counts - p).max() < 1e-3
+
+
+# ---- the model of the device algorithm (lsk_sample.h) against the reference-pinned functions -------------------
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        got = so.philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1])
+        assert [int(np.asarray(w).reshape(-1)[0]) for w in got] == want
+    u = so.device_uniforms(100000, 3, seed=1234, offset=7)
+    assert 0.0 < u.min() and u.max() < 1.0
+    assert abs(float(u.mean()) - 0.5) < 0.005 and abs(float(u.var()) - 1.0 / 12.0) < 0.002
+    assert not np.array_equal(u[:16], so.device_uniforms(16, 4, seed=1234, offset=7))       # the tag separates streams
+    assert not np.array_equal(u[:16], so.device_uniforms(16, 3, seed=1234, offset=8))       # so does the offset
+
+
+@pytest.mark.parametrize("idx", range(len(CASES)))
+def test_device_thresholds_keep_what_the_reference_keeps(idx):
+    """Key-space thresholds (device) vs sort + cumulative sum (HF): same kept set except that a group of EQUAL logits
+    straddling the nucleus boundary is kept whole on the device and split by sort order in HF."""
+    rec = CASES[idx]
+    for name in ("draft", "verify"):
+        logits = np.asarray(rec[name + "_logits"], dtype=np.float32)
+        keep, probs = so.device_warp(logits, rec["temperature"], rec["top_k"], rec["top_p"])
+        kept, gold_kept = set(np.flatnonzero(keep).tolist()), set(rec[name + "_kept"])
+        assert gold_kept <= kept, sorted(gold_kept - kept)
+        extra = kept - gold_kept
+        assert len({float(logits[i]) for i in extra}) <= 1
+        if extra:       # the extra members tie with the smallest logit HF kept
+            assert float(logits[next(iter(extra))]) == min(float(logits[i]) for i in gold_kept)
+        gold = np.asarray(rec[name + "_probs"], dtype=np.float64)
+        if not extra:
+            assert np.allclose(probs, gold, rtol=0, atol=3e-7)
+        else:           # same shape, renormalised over the slightly larger set
+            scale = gold[list(gold_kept)].sum() / probs[list(gold_kept)].astype(np.float64).sum()
+            assert np.allclose(probs[list(gold_kept)] * scale, gold[list(gold_kept)], rtol=0, atol=3e-7)
+
+
+def test_gumbel_max_draw_follows_the_warped_distribution():
+    rec = CASES[3]                                       # sharp case: a nucleus of a few tokens
+    logits = np.asarray(rec["verify_logits"], dtype=np.float32)
+    keep, probs = so.device_warp(logits, rec["temperature"], rec["top_k"], rec["top_p"])
+    n = 4000
+    counts = np.zeros_like(probs, dtype=np.float64)
+    for off in range(n):
+        tok, _ = so.device_sample_row(logits, rec["temperature"], rec["top_k"], rec["top_p"], seed=99, offset=off, tag=0)
+        assert keep[tok]
+        counts[tok] += 1
+    tv = 0.5 * np.abs(counts / n - probs).sum()
+    assert tv < 0.03, tv
+
+
+def test_device_accept_is_the_reference_loop():
+    rng = np.random.default_rng(5)
+    v = 64
+    for trial in range(200):
+        td = int(rng.integers(1, 6))
+        pd = [so.probabilities(rng.normal(size=v).astype(np.float32) * 2) for _ in range(td)]
+        pv = [so.probabilities(rng.normal(size=v).astype(np.float32) * 2) for _ in range(td + 1)]
+        drafts = [int(rng.choice(v, p=p.astype(np.float64) / p.astype(np.float64).sum())) for p in pd]
+        verified = [int(np.argmax(p)) for p in pv]
+        n, ntd, tok = so.device_accept(drafts, verified, pd, pv, eos=[], seed=11, offset=trial)
+        u = so.u01(so.philox4x32_10(np.arange(td), so.TAG_ACCEPT, trial, 0, 11, 0)[0])
+        n_ref, _ = so.accept_step(drafts, pd, pv, [float(x) for x in u], 0.5, bonus_token=verified[td])
+        assert (n, ntd) == (n_ref, td)
+        if n == td:
+            assert tok == verified[td]
+        else:
+            assert pv[n][tok] > pd[n][tok]
+    # a drafted EOS ends the draft: later drafts are neither tested nor counted
+    pd = [so.probabilities(rng.normal(size=v).astype(np.float32)) for _ in range(3)]
+    n, ntd, _ = so.device_accept([5, 9, 7], [5, 9, 7, 1], pd, pd + [pd[0]], eos=[9], seed=1, offset=0)
+    assert ntd == 2 and n == 2
