@@ -64,8 +64,10 @@ __host__ __device__ inline void lsk_philox4x32_10(unsigned int c0, unsigned int 
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// uniform in (0, 1) from the upper 24 bits
-__host__ __device__ inline float lsk_u01(unsigned int x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// uniform in (0, 1) from the upper 23 bits: (x >> 9) + 0.5 is exact in fp32, so neither 0 nor 1 can come out
+// (with 24 bits the top value rounds to 1.0 and its Gumbel is +inf: one element in 2^24, i.e. one 128K-row in 128,
+// would be drawn regardless of its probability)
+__host__ __device__ inline float lsk_u01(unsigned int x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 // ordered 16-bit key of a float (monotone in the value at bf16 resolution)
 __host__ __device__ inline int lsk_key16(float x) {

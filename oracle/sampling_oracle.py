@@ -122,7 +122,8 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def u01(bits: np.ndarray) -> np.ndarray:
-    return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    # 23 bits: (bits >> 9) + 0.5 is exact in fp32, so the result lies strictly inside (0, 1)
+    return ((bits >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
 
 
 def device_uniforms(n: int, tag: int, seed: int, offset: int) -> np.ndarray:
