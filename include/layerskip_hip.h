@@ -184,8 +184,9 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
                                      boundaries: DESIGN.md 3.3) */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
 /* ---- sampling on the device (sample=True; GenerationConfig temperature / top_k / top_p, generator_base.py:35-44) ----
- * EXPERIMENTAL in round 1: compiled and exported, exercised only by the opt-in tests (LSK_EXPERIMENTAL=1); the strategies'
- * default sampling path still materialises the logits for the host (hip_strategies.py).
+ * Round 1: both kernels are checked draw for draw against the oracle on the GPU (tests/test_gpu_zz_sampling.py);
+ * lsk_spec_step_sampled's end-to-end check is still opt-in (LSK_EXPERIMENTAL=1) and the strategies' default sampling
+ * path still materialises the logits for the host (hip_strategies.py).
  * Random numbers: Philox4x32-10, key = seed, counter = (element / 4, tag, offset); `offset` must differ between calls
  * that are to be independent (the strategies pass a step counter). */
 /* bytes of device scratch lsk_spec_step_sampled needs (logits + draft / verify probability rows, fp32) */

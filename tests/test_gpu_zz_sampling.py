@@ -1,7 +1,7 @@
 """Device-side sampling (lsk_sample.h) against the draw-for-draw model in oracle/sampling_oracle.py.
-OPT-IN: the kernels were written at the end of round 1 after the GPU budget was spent, so these checks only run
-with LSK_EXPERIMENTAL=1 until they have been seen green on hardware (then the guard goes away and
-`device_sampling` can become the strategies' default for sample=True)."""
+The two kernel checks were seen green on an MI355X at the end of round 1 and run by default.  The end-to-end check of
+lsk_spec_step_sampled (the orchestration around the two kernels) could not be run any more in that round: it stays
+behind LSK_EXPERIMENTAL=1, and so does the strategies' `device_sampling` switch, until it has been."""
 import ctypes
 import json
 import os
@@ -12,8 +12,8 @@ import torch
 
 from conftest import GOLDEN_DIR, build_case_model, load_golden
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("LSK_EXPERIMENTAL") != "1", reason="opt-in: set LSK_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
+experimental = pytest.mark.skipif(os.environ.get("LSK_EXPERIMENTAL") != "1", reason="opt-in: set LSK_EXPERIMENTAL=1")
 
 CASES = json.load(open(os.path.join(GOLDEN_DIR, "sampling", "cases.json")))
 SHAPE_OF_VOCAB = {512: "tiny-mha", 1000: "tiny-gqa", 768: "tiny-d64"}
@@ -83,6 +83,7 @@ def test_accept_sampled_kernel_matches_the_model(gpu_device):
         assert r[4:4 + n] == drafts[:n] and r[4 + n] == r[2]
 
 
+@experimental
 def test_device_sampled_generation_matches_the_host_path_in_distribution(gpu_device):
     from layerskip_amd import GenerationConfig
     from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
