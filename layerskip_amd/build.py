@@ -12,17 +12,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblayerskip_hip.so")
 SOURCES = ["layerskip_hip.hip"]
-HEADERS = ["lsk_common.h", "lsk_gemm.h", "lsk_attn.h", os.path.join("..", "..", "include", "layerskip_hip.h")]
+
+
+def _inputs():
+    """Everything the translation unit reads: the .hip sources, EVERY kernel header next to them, the public header."""
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(HERE, "..", "include", "layerskip_hip.h"))
+    return files
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return False
+    return any(os.path.getmtime(f) > t for f in _inputs())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
