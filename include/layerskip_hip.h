@@ -70,6 +70,9 @@ typedef struct lsk_step_result {
 
 const char* lsk_last_error(void);
 int lsk_abi_version(void);
+/* Model dtype this build of the library computes in: 0 = bf16 (liblayerskip_hip.so), 1 = fp16
+ * (liblayerskip_hip_f16.so, same sources with -DLSK_ELEM_F16; the dtype generate.py:63 hard-codes). */
+int lsk_elem_dtype(void);
 
 /* ---- sizes ---------------------------------------------------------------------------- */
 int lsk_workspace_bytes(const lsk_config* cfg, size_t* out_bytes);

@@ -20,7 +20,10 @@ LSK_OPT_FUSED_OPROJ = 4
 LSK_OPT_FLASH_PREFILL = 5
 LSK_OPT_CHAIN = 6            # chained projection phases in one resident grid (bit-identical, measured slower; default off)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblayerskip_hip.so")
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "liblayerskip_hip.so")            # bf16 build (BASELINE configs)
+LIB_PATH_F16 = os.path.join(_CSRC, "liblayerskip_hip_f16.so")    # fp16 build (same sources, -DLSK_ELEM_F16)
+DTYPE_CODES = {"bf16": 0, "fp16": 1}
 
 
 class LskConfig(ctypes.Structure):
@@ -45,6 +48,7 @@ class LskStepResult(ctypes.Structure):
 PROTOTYPES = {
     "lsk_last_error": (c_char_p, []),
     "lsk_abi_version": (c_int32, []),
+    "lsk_elem_dtype": (c_int32, []),
     "lsk_workspace_bytes": (c_int32, [POINTER(LskConfig), POINTER(c_size_t)]),
     "lsk_kv_pool_bytes": (c_int32, [POINTER(LskConfig), POINTER(c_size_t)]),
     "lsk_packed_bytes": (c_int32, [c_int32, c_int32, POINTER(c_size_t)]),
@@ -86,19 +90,21 @@ PROTOTYPES = {
     "lsk_engine_get_profile": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32)]),
 }
 
-_LIB = None
+_LIBS: dict = {}
 
 
 class LskError(RuntimeError):
     """An entry point of liblayerskip_hip.so returned a non-zero status."""
 
 
-def load(path: str | None = None) -> ctypes.CDLL:
-    """Load the HIP extension (once) and type every exported symbol.  Raises if anything is missing."""
-    global _LIB
-    if _LIB is not None and path is None:
-        return _LIB
-    path = path or LIB_PATH
+def load(path: str | None = None, dtype: str = "bf16") -> ctypes.CDLL:
+    """Load the HIP extension for a model dtype (once) and type every exported symbol.  Raises if anything is missing."""
+    if dtype not in DTYPE_CODES:
+        raise LskError(f"unsupported model dtype {dtype!r} (bf16 or fp16)")
+    if path is None and dtype in _LIBS:
+        return _LIBS[dtype]
+    explicit = path is not None
+    path = path or (LIB_PATH if dtype == "bf16" else LIB_PATH_F16)
     import torch  # noqa: F401  -- loads the ROCm runtime (libamdhip64.so.7) the extension links against
     if not os.path.exists(path):
         raise LskError(
@@ -114,11 +120,15 @@ def load(path: str | None = None) -> ctypes.CDLL:
         fn.argtypes = argtypes
     if lib.lsk_abi_version() != LSK_ABI_VERSION:
         raise LskError(f"ABI mismatch: library {lib.lsk_abi_version()} vs binding {LSK_ABI_VERSION}")
-    _LIB = lib
+    if not explicit and lib.lsk_elem_dtype() != DTYPE_CODES[dtype]:
+        raise LskError(f"{path} computes in dtype code {lib.lsk_elem_dtype()}, expected {dtype}")
+    if not explicit:
+        _LIBS[dtype] = lib
     return lib
 
 
-def check(status: int) -> None:
+def check(status: int, lib: ctypes.CDLL | None = None) -> None:
+    """Raise LskError with the library's (thread-local) message for a non-zero status."""
     if status != 0:
-        msg = load().lsk_last_error()
+        msg = (lib or load()).lsk_last_error()
         raise LskError(msg.decode("utf-8", "replace") if msg else f"liblayerskip_hip status {status}")

@@ -10,7 +10,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(CSRC, "liblayerskip_hip.so")
+LIB = os.path.join(CSRC, "liblayerskip_hip.so")              # bf16: the BASELINE configs
+LIB_F16 = os.path.join(CSRC, "liblayerskip_hip_f16.so")      # fp16: same sources, -DLSK_ELEM_F16 (generate.py:63's dtype)
 SOURCES = ["layerskip_hip.hip"]
 
 
@@ -21,27 +22,32 @@ def _inputs():
     return files
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib: str) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(f) > t for f in _inputs())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
+def _compile(lib: str, defines, verbose: bool) -> None:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function"] + list(defines) + ["-o", lib] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         sys.stderr.write(proc.stdout + proc.stderr)
-        raise RuntimeError("hipcc failed building liblayerskip_hip.so")
+        raise RuntimeError(f"hipcc failed building {os.path.basename(lib)}")
     if verbose and proc.stderr:
         sys.stderr.write(proc.stderr)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Builds both libraries in-tree (when stale); returns the bf16 one."""
+    for lib, defines in ((LIB, []), (LIB_F16, ["-DLSK_ELEM_F16"])):
+        if force or _stale(lib):
+            _compile(lib, defines, verbose)
     return LIB
 
 

@@ -49,12 +49,13 @@ static int lsk_fail(const char* fmt, ...) {
 
 extern "C" const char* lsk_last_error(void) { return g_err; }
 extern "C" int lsk_abi_version(void) { return LSK_ABI_VERSION; }
+extern "C" int lsk_elem_dtype(void) { return LSK_ELEM_DTYPE; }
 
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
 // nn.Linear weight -> 16x32 MFMA B-fragment tiles.  One thread moves one lane-fragment (16 B).
-__global__ void lsk_pack_kernel(const bf16_t* __restrict__ src, int n_rows, int k, int ld_src, bf16_t* __restrict__ dst,
+__global__ void lsk_pack_kernel(const elem_t* __restrict__ src, int n_rows, int k, int ld_src, elem_t* __restrict__ dst,
                                 int dst_tile_offset, int dst_tile_stride, int rope_hd) {
     const int ksteps = k >> 5;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,30 +76,30 @@ __global__ void lsk_pack_kernel(const bf16_t* __restrict__ src, int n_rows, int 
         const int feat = (cc < 8) ? (tt * 8 + cc) : ((rope_hd >> 1) + tt * 8 + (cc - 8));
         srow = head * rope_hd + feat;
     }
-    bf16x8 v;
+    elem8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.0f;
-    if (srow < n_rows) v = *(const bf16x8*)(src + (size_t)srow * ld_src + s * 32 + (lane >> 4) * 8);
+    for (int j = 0; j < 8; ++j) v[j] = (elem_t)0.0f;
+    if (srow < n_rows) v = *(const elem8*)(src + (size_t)srow * ld_src + s * 32 + (lane >> 4) * 8);
     const size_t dt = (size_t)dst_tile_offset + (size_t)t * dst_tile_stride;
-    *(bf16x8*)(dst + ((dt * ksteps + s) * 64 + lane) * 8) = v;
+    *(elem8*)(dst + ((dt * ksteps + s) * 64 + lane) * 8) = v;
 }
 
 // h[row_base + i] = embed[tokens[i]]   (tokens on device)
-__global__ void lsk_embed_kernel(const bf16_t* __restrict__ embed, const int* __restrict__ tokens, int hidden, int vocab,
-                                 bf16_t* __restrict__ h) {
+__global__ void lsk_embed_kernel(const elem_t* __restrict__ embed, const int* __restrict__ tokens, int hidden, int vocab,
+                                 elem_t* __restrict__ h) {
     const int row = blockIdx.x;
     int tok = tokens[row];
     tok = min(max(tok, 0), vocab - 1);
-    const bf16x8* src = (const bf16x8*)(embed + (size_t)tok * hidden);
-    bf16x8* dst = (bf16x8*)(h + (size_t)row * hidden);
+    const elem8* src = (const elem8*)(embed + (size_t)tok * hidden);
+    elem8* dst = (elem8*)(h + (size_t)row * hidden);
     for (int i = threadIdx.x; i < hidden / 8; i += blockDim.x) dst[i] = src[i];
 }
 
 // final argmax over the per-workgroup partials of the lm_head kernel (lowest index wins ties); optionally the
 // embedding row of the chosen token is copied straight into the next draft row (saves one launch per draft)
 __global__ void lsk_argmax_finalize_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int n_parts,
-                                           int m, int* __restrict__ tokens_out, const bf16_t* __restrict__ embed, int hidden,
-                                           int vocab, bf16_t* __restrict__ embed_dst) {
+                                           int m, int* __restrict__ tokens_out, const elem_t* __restrict__ embed, int hidden,
+                                           int vocab, elem_t* __restrict__ embed_dst) {
     __shared__ int s_tok;
     const int row = blockIdx.x;
     if (row >= m) return;
@@ -121,8 +122,8 @@ __global__ void lsk_argmax_finalize_kernel(const float* __restrict__ part_val, c
     if (embed_dst == nullptr) return;
     __syncthreads();
     const int tok = min(max(s_tok, 0), vocab - 1);
-    const bf16x8* src = (const bf16x8*)(embed + (size_t)tok * hidden);
-    bf16x8* dst = (bf16x8*)(embed_dst + (size_t)row * hidden);
+    const elem8* src = (const elem8*)(embed + (size_t)tok * hidden);
+    elem8* dst = (elem8*)(embed_dst + (size_t)row * hidden);
     for (int i = threadIdx.x; i < hidden / 8; i += blockDim.x) dst[i] = src[i];
 }
 
@@ -181,13 +182,13 @@ __global__ void lsk_set_state_kernel(StepState* st, int kv_len, int add) {
 // engine
 // ------------------------------------------------------------------------------------------------
 struct LayerWeights {
-    const bf16_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr, *norm1 = nullptr, *norm2 = nullptr;
+    const elem_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr, *norm1 = nullptr, *norm2 = nullptr;
 };
 
 struct lsk_engine {
     lsk_config cfg;
     std::vector<LayerWeights> layers;
-    const bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    const elem_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_len = 0;
     // device workspace carve
     unsigned char* ws = nullptr;
@@ -202,11 +203,11 @@ struct lsk_engine {
     int* bulk_ids = nullptr;      // [max_prompt]
     float* part_val = nullptr;    // [max_parts][16]
     int* part_idx = nullptr;
-    bf16_t* hrow = nullptr;       // [16][H]
-    bf16_t* hbulk = nullptr;      // [max_prompt][H]
-    bf16_t* qbuf = nullptr;       // [16][n_heads*hd]
-    bf16_t* attn = nullptr;       // [16][n_heads*hd]
-    bf16_t* act = nullptr;        // [16][I]
+    elem_t* hrow = nullptr;       // [16][H]
+    elem_t* hbulk = nullptr;      // [max_prompt][H]
+    elem_t* qbuf = nullptr;       // [16][n_heads*hd]
+    elem_t* attn = nullptr;       // [16][n_heads*hd]
+    elem_t* act = nullptr;        // [16][I]
     float* attn_part = nullptr;   // [n_heads][n_pages][16][hd + 2] split-KV partials
     int* attn_cnt = nullptr;      // [n_heads] arrival tickets of the in-launch combine, then heads_done
     int* heads_done = nullptr;    // monotonic: += n_heads per fused attention+o_proj launch
@@ -219,8 +220,8 @@ struct lsk_engine {
     int chain_base = 0;           // value of the counters before the next chained launch
     int n_cus = 0;                // compute units of the device (co-residency bound of a chained grid)
     bool chain_attr_done = false;
-    bf16_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]
-    bf16_t* kv_pool = nullptr;
+    elem_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]
+    elem_t* kv_pool = nullptr;
     size_t kv_layer_elems = 0;    // elements per layer (K and V)
     size_t kv_half_elems = 0;     // elements of K (or V) per layer
     int max_parts = 0;
@@ -321,8 +322,8 @@ extern "C" int lsk_pack_linear(const void* src, int32_t n_rows, int32_t k, int32
     const long long total = (long long)((n_rows + 15) / 16) * (k / 32) * 64;
     const int threads = 256;
     const long long blocks = (total + threads - 1) / threads;
-    hipLaunchKernelGGL(lsk_pack_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)src, n_rows, k,
-                       ld_src, (bf16_t*)dst, dst_tile_offset, dst_tile_stride, rope_head_dim);
+    hipLaunchKernelGGL(lsk_pack_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, (const elem_t*)src, n_rows, k,
+                       ld_src, (elem_t*)dst, dst_tile_offset, dst_tile_stride, rope_head_dim);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -389,20 +390,20 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->bulk_ids = (int*)(e->ws + L.bulk_ids);
     e->part_val = (float*)(e->ws + L.part_val);
     e->part_idx = (int*)(e->ws + L.part_idx);
-    e->hrow = (bf16_t*)(e->ws + L.hrow);
-    e->hbulk = (bf16_t*)(e->ws + L.hbulk);
-    e->qbuf = (bf16_t*)(e->ws + L.qbuf);
-    e->attn = (bf16_t*)(e->ws + L.attn);
-    e->act = (bf16_t*)(e->ws + L.act);
+    e->hrow = (elem_t*)(e->ws + L.hrow);
+    e->hbulk = (elem_t*)(e->ws + L.hbulk);
+    e->qbuf = (elem_t*)(e->ws + L.qbuf);
+    e->attn = (elem_t*)(e->ws + L.attn);
+    e->act = (elem_t*)(e->ws + L.act);
     e->attn_part = (float*)(e->ws + L.attn_part);
     e->attn_cnt = (int*)(e->ws + L.attn_cnt);
     e->heads_done = e->attn_cnt + cfg->n_heads;
     e->chain_ctr = e->attn_cnt + cfg->n_heads + 16;
-    e->xn_bulk = (bf16_t*)(e->ws + L.xn_bulk);
-    e->q_bulk = (bf16_t*)(e->ws + L.q_bulk);
-    e->attn_bulk = (bf16_t*)(e->ws + L.attn_bulk);
-    e->act_bulk = (bf16_t*)(e->ws + L.act_bulk);
-    e->kv_pool = (bf16_t*)kv_pool;
+    e->xn_bulk = (elem_t*)(e->ws + L.xn_bulk);
+    e->q_bulk = (elem_t*)(e->ws + L.q_bulk);
+    e->attn_bulk = (elem_t*)(e->ws + L.attn_bulk);
+    e->act_bulk = (elem_t*)(e->ws + L.act_bulk);
+    e->kv_pool = (elem_t*)kv_pool;
     e->kv_half_elems = (size_t)cfg->max_ctx * cfg->n_kv_heads * cfg->head_dim;
     e->kv_layer_elems = 2 * e->kv_half_elems;
     e->max_parts = L.max_parts;
@@ -437,8 +438,8 @@ extern "C" int lsk_engine_set_layer(lsk_engine* e, int32_t layer, const void* wq
     if (!e || layer < 0 || layer >= e->cfg.num_layers) return lsk_fail("lsk_engine_set_layer: bad layer %d", layer);
     if (!wqkv || !wo || !wgu || !wdown || !norm1 || !norm2) return lsk_fail("lsk_engine_set_layer: null weight");
     LayerWeights& lw = e->layers[layer];
-    lw.wqkv = (const bf16_t*)wqkv; lw.wo = (const bf16_t*)wo; lw.wgu = (const bf16_t*)wgu; lw.wdown = (const bf16_t*)wdown;
-    lw.norm1 = (const bf16_t*)norm1; lw.norm2 = (const bf16_t*)norm2;
+    lw.wqkv = (const elem_t*)wqkv; lw.wo = (const elem_t*)wo; lw.wgu = (const elem_t*)wgu; lw.wdown = (const elem_t*)wdown;
+    lw.norm1 = (const elem_t*)norm1; lw.norm2 = (const elem_t*)norm2;
     return 0;
 }
 
@@ -446,8 +447,8 @@ extern "C" int lsk_engine_set_globals(lsk_engine* e, const void* embed, const vo
                                       const void* rope_sin, int32_t rope_len) {
     if (!e || !embed || !final_norm || !lm_head || !rope_cos || !rope_sin) return lsk_fail("lsk_engine_set_globals: null pointer");
     if (rope_len < e->cfg.max_ctx) return lsk_fail("rope table (%d) shorter than max_ctx (%d)", rope_len, e->cfg.max_ctx);
-    e->embed = (const bf16_t*)embed; e->final_norm = (const bf16_t*)final_norm; e->lm_head = (const bf16_t*)lm_head;
-    e->rope_cos = (const bf16_t*)rope_cos; e->rope_sin = (const bf16_t*)rope_sin; e->rope_len = rope_len;
+    e->embed = (const elem_t*)embed; e->final_norm = (const elem_t*)final_norm; e->lm_head = (const elem_t*)lm_head;
+    e->rope_cos = (const elem_t*)rope_cos; e->rope_sin = (const elem_t*)rope_sin; e->rope_len = rope_len;
     return 0;
 }
 
@@ -531,7 +532,7 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
     return 0;
 }
 
-static bf16_t* buf_rows(lsk_engine* e, int buffer, int row_base) {
+static elem_t* buf_rows(lsk_engine* e, int buffer, int row_base) {
     return (buffer == 0 ? e->hrow : e->hbulk) + (size_t)row_base * e->cfg.hidden;
 }
 
@@ -543,7 +544,7 @@ static int check_rows(lsk_engine* e, int buffer, int row_base, int m) {
     return 0;
 }
 
-static int attn_params(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t* kpool, const bf16_t* vpool, int m, int pos_off,
+static int attn_params(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t* kpool, const elem_t* vpool, int m, int pos_off,
                        AttnSplitParams& sp, int& pages) {
     const lsk_config& c = e->cfg;
     const int hd = c.head_dim;
@@ -562,7 +563,7 @@ static int attn_params(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t
     return 0;
 }
 
-static int launch_attn(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t* kpool, const bf16_t* vpool, int m, int pos_off, hipStream_t st) {
+static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t* kpool, const elem_t* vpool, int m, int pos_off, hipStream_t st) {
     const lsk_config& c = e->cfg;
     const int hd = c.head_dim;
     AttnSplitParams sp;
@@ -583,7 +584,7 @@ static int launch_attn(lsk_engine* e, const bf16_t* q, bf16_t* out, const bf16_t
 }
 
 // attention + o_proj/residual of one layer as ONE role-pipelined launch (lsk_fused.h); m <= 8
-static int launch_attn_oproj(lsk_engine* e, const bf16_t* kpool, const bf16_t* vpool, const LayerWeights& lw, bf16_t* x, int m,
+static int launch_attn_oproj(lsk_engine* e, const elem_t* kpool, const elem_t* vpool, const LayerWeights& lw, elem_t* x, int m,
                              int pos_off, hipStream_t st) {
     const lsk_config& c = e->cfg;
     const int hd = c.head_dim;
@@ -616,7 +617,7 @@ static int launch_attn_oproj(lsk_engine* e, const bf16_t* kpool, const bf16_t* v
 
 // o_proj -> gate/up -> down [-> QKV of layer l + 1] of one layer as ONE resident grid (lsk_chain.h).  Returns with
 // *chained = false (nothing launched) when the shape does not allow it: the caller then uses the separate launches.
-static int launch_chain(lsk_engine* e, int l, bool with_next_qkv, bf16_t* x, int m, const int* base_ptr, int pos_off, hipStream_t st,
+static int launch_chain(lsk_engine* e, int l, bool with_next_qkv, elem_t* x, int m, const int* base_ptr, int pos_off, hipStream_t st,
                         bool* chained) {
     const lsk_config& c = e->cfg;
     const int qdim = c.n_heads * c.head_dim;
@@ -663,7 +664,7 @@ static int launch_chain(lsk_engine* e, int l, bool with_next_qkv, bf16_t* x, int
     if (lsk_gemm_lds_bytes(m, cp.o.K) > lds) lds = lsk_gemm_lds_bytes(m, cp.o.K);
     if (with_next_qkv) {   // next layer: input RMSNorm -> q/k/v -> RoPE -> KV append
         const LayerWeights& nw = e->layers[l + 1];
-        bf16_t* kpool = e->kv_pool + (size_t)(l + 1) * e->kv_layer_elems;
+        elem_t* kpool = e->kv_pool + (size_t)(l + 1) * e->kv_layer_elems;
         GemmParams& p = cp.qkv;
         p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = qdim + 2 * kvdim; p.n_tiles = p.N / 16;
         p.wp = nw.wqkv; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
@@ -719,15 +720,15 @@ static int profile_pair(lsk_engine* e, hipEvent_t* a, hipEvent_t* b) {
 }
 
 // decoder layers [lb, le) in place over rows of `x` (positions *base_ptr + pos_off + i)
-static int run_layers(lsk_engine* e, bf16_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st) {
+static int run_layers(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st) {
     const lsk_config& c = e->cfg;
     const int qdim = c.n_heads * c.head_dim;
     const int kvdim = c.n_kv_heads * c.head_dim;
     bool qkv_done = false;      // the chained launch of layer l - 1 already ran this layer's q/k/v projection
     for (int l = lb; l < le; ++l) {
         const LayerWeights& lw = e->layers[l];
-        bf16_t* kpool = e->kv_pool + (size_t)l * e->kv_layer_elems;
-        bf16_t* vpool = kpool + e->kv_half_elems;
+        elem_t* kpool = e->kv_pool + (size_t)l * e->kv_layer_elems;
+        elem_t* vpool = kpool + e->kv_half_elems;
         if (!qkv_done) {   // input RMSNorm -> q/k/v projections -> RoPE -> KV append
             GemmParams p{};
             p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden;
@@ -778,8 +779,8 @@ static int run_layers(lsk_engine* e, bf16_t* x, int m, const int* base_ptr, int 
 }
 
 // final norm + lm_head + argmax over rows of x; tokens land in tokens_dev[0..m)
-static int run_head(lsk_engine* e, const bf16_t* x, int m, float* logits, int ld_logits, int* tokens_dev, hipStream_t st,
-                    bf16_t* embed_dst = nullptr) {
+static int run_head(lsk_engine* e, const elem_t* x, int m, float* logits, int ld_logits, int* tokens_dev, hipStream_t st,
+                    elem_t* embed_dst = nullptr) {
     const lsk_config& c = e->cfg;
     GemmParams p{};
     p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = c.vocab; p.n_tiles = (c.vocab + 15) / 16;
@@ -795,7 +796,7 @@ static int run_head(lsk_engine* e, const bf16_t* x, int m, float* logits, int ld
     return 0;
 }
 
-static int embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, bf16_t* dst, hipStream_t st) {
+static int embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, elem_t* dst, hipStream_t st) {
     hipLaunchKernelGGL(lsk_embed_kernel, dim3(n), dim3(256), 0, st, e->embed, tokens_dev, e->cfg.hidden, e->cfg.vocab, dst);
     HIP_OK(hipGetLastError());
     return 0;
@@ -823,8 +824,8 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
     const int* kvp = &e->state->kv_len;
     for (int l = lb; l < le; ++l) {
         const LayerWeights& lw = e->layers[l];
-        bf16_t* kpool = e->kv_pool + (size_t)l * e->kv_layer_elems;
-        bf16_t* vpool = kpool + e->kv_half_elems;
+        elem_t* kpool = e->kv_pool + (size_t)l * e->kv_layer_elems;
+        elem_t* vpool = kpool + e->kv_half_elems;
         hipLaunchKernelGGL(lsk_rmsnorm_rows_kernel, dim3(n), dim3(256), 0, st, e->hbulk, c.hidden, lw.norm1, c.rms_eps, c.hidden, e->xn_bulk, c.hidden);
         HIP_OK(hipGetLastError());
         {
@@ -928,7 +929,7 @@ static int enqueue_step(lsk_engine* e, int P, int S, int E, int n_eos, int slot,
     }
     // ---- draft loop (SSG:127-148), device resident: row j = input token (j = 0) or draft j ----
     for (int j = 0; j <= S; ++j) {
-        bf16_t* xr = e->hrow + (size_t)j * c.hidden;
+        elem_t* xr = e->hrow + (size_t)j * c.hidden;
         if (j == 0) LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, xr, st));   // rows j > 0 were embedded by the previous head
         LSK_TRY(run_layers(e, xr, 1, kvp, P - 1 + j, 0, E, st));   // j == S: forward_remainder's early pass (LMU:350-362)
         if (j < S) LSK_TRY(run_head(e, xr, 1, nullptr, 0, e->row_tokens + j + 1, st, xr + c.hidden));
@@ -1239,7 +1240,7 @@ static int check_sampling_args(float temperature, float top_p) {
 }
 
 static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, float temperature, int top_k, float top_p, uint64_t seed,
-                         uint64_t offset, int tag0, int* tokens_dev, float* probs, bf16_t* embed_dst, hipStream_t st) {
+                         uint64_t offset, int tag0, int* tokens_dev, float* probs, elem_t* embed_dst, hipStream_t st) {
     SampleParams sp{};
     sp.logits = logits; sp.ld = ld; sp.vocab = e->cfg.vocab; sp.inv_temperature = 1.0f / temperature;
     sp.top_k = top_k; sp.top_p = top_p;
@@ -1314,7 +1315,7 @@ extern "C" int lsk_spec_step_sampled(lsk_engine* e, const int32_t* input_ids, in
     }
     int* greedy_scratch = e->verified;      // the head kernel's argmax lands here and is ignored
     for (int j = 0; j <= S; ++j) {
-        bf16_t* xr = e->hrow + (size_t)j * c.hidden;
+        elem_t* xr = e->hrow + (size_t)j * c.hidden;
         if (j == 0) LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, xr, st));
         LSK_TRY(run_layers(e, xr, 1, kvp, P - 1 + j, 0, E, st));
         if (j < S) {
@@ -1360,9 +1361,9 @@ extern "C" int lsk_test_gemm(const void* x, int32_t m, int32_t k, const void* w_
     if (m < 1 || m > LSK_MAX_ROWS || k <= 0 || (k % 32) || n_rows <= 0) return lsk_fail("lsk_test_gemm: bad shape m=%d k=%d n=%d", m, k, n_rows);
     LSK_TRY(init_kernel_attrs());
     GemmParams p{};
-    p.x = (const bf16_t*)x; p.ldx = k; p.M = m; p.K = k; p.N = n_rows; p.n_tiles = (n_rows + 15) / 16;
-    p.wp = (const bf16_t*)w_packed; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * k * 2);
-    p.norm_w = (const bf16_t*)norm_w; p.eps = eps; p.y = y;
+    p.x = (const elem_t*)x; p.ldx = k; p.M = m; p.K = k; p.N = n_rows; p.n_tiles = (n_rows + 15) / 16;
+    p.wp = (const elem_t*)w_packed; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * k * 2);
+    p.norm_w = (const elem_t*)norm_w; p.eps = eps; p.y = y;
     const int tw = target_wgs > 0 ? target_wgs : 256;
     return norm_w ? launch_gemm<PRO_RMS, EPI_F32>(p, tw, (hipStream_t)stream) : launch_gemm<PRO_PLAIN, EPI_F32>(p, tw, (hipStream_t)stream);
 }

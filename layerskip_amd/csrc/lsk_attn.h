@@ -31,10 +31,10 @@
 #define LSK_ATTN_PAGE 128          // keys per workgroup == KV page size
 
 struct AttnSplitParams {
-    const bf16_t* q;        // [M][ldq]
+    const elem_t* q;        // [M][ldq]
     int ldq;
-    const bf16_t* kpool;    // this layer's K pages  [page][n_kv][page_size][head_dim]
-    const bf16_t* vpool;    // this layer's V^T pages [page][n_kv][head_dim][page_size]
+    const elem_t* kpool;    // this layer's K pages  [page][n_kv][page_size][head_dim]
+    const elem_t* vpool;    // this layer's V^T pages [page][n_kv][head_dim][page_size]
     const int* block_table;
     int n_kv;
     int group;              // n_heads / n_kv
@@ -45,7 +45,7 @@ struct AttnSplitParams {
     float* part;            // [n_heads][max_pages][16][HD + 2]
     int max_pages;
     int* counters;          // [n_heads] arrival tickets (self-resetting); nullptr = separate combine kernel
-    bf16_t* out;            // [M][ldo] attention output (written by the last-arriving page of a head)
+    elem_t* out;            // [M][ldo] attention output (written by the last-arriving page of a head)
     int ldo;
     int n_pages;            // page-workgroups per head in this launch
     int* heads_done;        // optional: bumped once per head after its output rows are published (write-through),
@@ -62,7 +62,7 @@ struct AttnCombineParams {
     int M;
     const int* kv_len;
     int pos_off;
-    bf16_t* out;            // [M][ldo]
+    elem_t* out;            // [M][ldo]
     int ldo;
 };
 
@@ -91,25 +91,25 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
     // ---- every load of this wave up front ----
     const int page = p.block_table[page_l];
     const size_t head_base = ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD;
-    const bf16_t* kp = p.kpool + head_base + (size_t)(w * 32 + c16) * HD + g * 8;
-    const bf16_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + w * 32 + g * 8;
-    const bf16_t* qp = p.q + (size_t)min(c16, M - 1) * p.ldq + head * HD + g * 8;
-    bf16x8 kb[2][KS], vb[DT], qa[KS];
+    const elem_t* kp = p.kpool + head_base + (size_t)(w * 32 + c16) * HD + g * 8;
+    const elem_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + w * 32 + g * 8;
+    const elem_t* qp = p.q + (size_t)min(c16, M - 1) * p.ldq + head * HD + g * 8;
+    elem8 kb[2][KS], vb[DT], qa[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        kb[0][ks] = *(const bf16x8*)(kp + ks * 32);
-        kb[1][ks] = *(const bf16x8*)(kp + 16 * HD + ks * 32);
-        qa[ks] = *(const bf16x8*)(qp + ks * 32);
+        kb[0][ks] = *(const elem8*)(kp + ks * 32);
+        kb[1][ks] = *(const elem8*)(kp + 16 * HD + ks * 32);
+        qa[ks] = *(const elem8*)(qp + ks * 32);
     }
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const bf16x8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
+    for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
 
     // ---- S = Q K^T (C layout: column = key, rows g*4 + r) ----
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[0][ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[1][ks], s1, 0, 0, 0);
+        s0 = LSK_MFMA_16x16x32(qa[ks], kb[0][ks], s0, 0, 0, 0);
+        s1 = LSK_MFMA_16x16x32(qa[ks], kb[1][ks], s1, 0, 0, 0);
     }
     const int keyA = key0 + w * 32 + c16;    // key of s0's column; s1's is keyA + 16
     float mrow[4], lrow[4];
@@ -130,19 +130,19 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
         l = row16_sum(l);
         mrow[r] = m;
         lrow[r] = l;
-        *(bf16_t*)(pw + row * PB_STRIDE + c16 * 2) = f2bf(p0);
-        *(bf16_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2bf(p1);
+        *(elem_t*)(pw + row * PB_STRIDE + c16 * 2) = f2e(p0);
+        *(elem_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2e(p1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- O = P V : A fragment = P[row c16][keys g*8 .. g*8+7] ----
-    const bf16x8 pa = *(const bf16x8*)(pw + c16 * PB_STRIDE + g * 16);
+    const elem8 pa = *(const elem8*)(pw + c16 * PB_STRIDE + g * 16);
     float* dst = sm + (size_t)w * 16 * PSTRIDE;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb[dt], o, 0, 0, 0);
+        o = LSK_MFMA_16x16x32(pa, vb[dt], o, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[(g * 4 + r) * PSTRIDE + dt * 16 + c16] = o[r];
     }
@@ -221,7 +221,7 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
                 }
             }
         }
-        const bf16_t o0 = f2bf(a0 / l), o1 = f2bf(a1 / l);
+        const elem_t o0 = f2e(a0 / l), o1 = f2e(a1 / l);
         const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
         unsigned* op = (unsigned*)(p.out + (size_t)r * p.ldo + head * HD + d);
         if (publish) __hip_atomic_store(op, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineP
             }
         }
     }
-    p.out[(size_t)row * p.ldo + head * HD + d] = f2bf(a / l);
+    p.out[(size_t)row * p.ldo + head * HD + d] = f2e(a / l);
 }
 
 // ---- prompt-prefill attention: 16 query rows x all visible keys per workgroup, online softmax (flash shape) ----
@@ -281,12 +281,12 @@ __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineP
 // 1 KiB of LDS per wave.  The 4 waves are merged in a fixed order at the end.  One launch per layer replaces the
 // rows/16 launches of the decode kernel; only prompt rows that are not decision rows go through it.
 struct AttnPrefillParams {
-    const bf16_t* q;        // [rows][ldq]
+    const elem_t* q;        // [rows][ldq]
     int ldq;
-    bf16_t* out;            // [rows][ldo]
+    elem_t* out;            // [rows][ldo]
     int ldo;
-    const bf16_t* kpool;
-    const bf16_t* vpool;
+    const elem_t* kpool;
+    const elem_t* vpool;
     const int* block_table;
     int n_kv;
     int group;
@@ -318,10 +318,10 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(cons
     const int last_key = base_pos + M - 1;
     const int n_pages = last_key / LSK_ATTN_PAGE + 1;
 
-    const bf16_t* qp = p.q + (size_t)(r0 + min(c16, M - 1)) * p.ldq + head * HD + g * 8;
-    bf16x8 qa[KS];
+    const elem_t* qp = p.q + (size_t)(r0 + min(c16, M - 1)) * p.ldq + head * HD + g * 8;
+    elem8 qa[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qa[ks] = *(const bf16x8*)(qp + ks * 32);
+    for (int ks = 0; ks < KS; ++ks) qa[ks] = *(const elem8*)(qp + ks * 32);
 
     float mrun[4], lrun[4];
     f32x4 o[DT];
@@ -337,21 +337,21 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(cons
         for (int sb = 0; sb < 4; ++sb) {
             const int key0 = pg * LSK_ATTN_PAGE + sb * 32;
             if (key0 > last_key) break;
-            const bf16_t* kp = p.kpool + head_base + (size_t)(sb * 32 + c16) * HD + g * 8;
-            const bf16_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + sb * 32 + g * 8;
-            bf16x8 kb[2][KS], vb[DT];
+            const elem_t* kp = p.kpool + head_base + (size_t)(sb * 32 + c16) * HD + g * 8;
+            const elem_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + sb * 32 + g * 8;
+            elem8 kb[2][KS], vb[DT];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                kb[0][ks] = *(const bf16x8*)(kp + ks * 32);
-                kb[1][ks] = *(const bf16x8*)(kp + 16 * HD + ks * 32);
+                kb[0][ks] = *(const elem8*)(kp + ks * 32);
+                kb[1][ks] = *(const elem8*)(kp + 16 * HD + ks * 32);
             }
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const bf16x8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
+            for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[0][ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[1][ks], s1, 0, 0, 0);
+                s0 = LSK_MFMA_16x16x32(qa[ks], kb[0][ks], s0, 0, 0, 0);
+                s1 = LSK_MFMA_16x16x32(qa[ks], kb[1][ks], s1, 0, 0, 0);
             }
             const int keyA = key0 + c16;
             float alpha[4];
@@ -373,18 +373,18 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(cons
                 l = row16_sum(l);
                 lrun[r] = lrun[r] * alpha[r] + l;
                 mrun[r] = mn;
-                *(bf16_t*)(pw + row * PB_STRIDE + c16 * 2) = f2bf(p0);
-                *(bf16_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2bf(p1);
+                *(elem_t*)(pw + row * PB_STRIDE + c16 * 2) = f2e(p0);
+                *(elem_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2e(p1);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const bf16x8 pa = *(const bf16x8*)(pw + c16 * PB_STRIDE + g * 16);
+            const elem8 pa = *(const elem8*)(pw + c16 * PB_STRIDE + g * 16);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[dt][r] *= alpha[r];
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb[dt], o[dt], 0, 0, 0);
+                o[dt] = LSK_MFMA_16x16x32(pa, vb[dt], o[dt], 0, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();     // P of the next sub-block must not overwrite before the read above
         }
@@ -416,6 +416,6 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(cons
             a += src[d] * f;
             l += src[HD + 1] * f;
         }
-        p.out[(size_t)(r0 + r) * p.ldo + head * HD + d] = f2bf(a / l);
+        p.out[(size_t)(r0 + r) * p.ldo + head * HD + d] = f2e(a / l);
     }
 }

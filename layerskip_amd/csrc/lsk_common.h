@@ -4,8 +4,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The model dtype is a BUILD-time choice: the same sources give liblayerskip_hip.so (bf16, the BASELINE configs) and,
+// with -DLSK_ELEM_F16, liblayerskip_hip_f16.so (fp16, the dtype the reference's generate.py hard-codes, generate.py:63).
+// Everything below is written against elem_t: storage, the rounding points (f2e / rnd_e) and the MFMA instruction.
+#ifdef LSK_ELEM_F16
+typedef _Float16 elem_t;
+typedef _Float16 elem8 __attribute__((ext_vector_type(8)));
+#define LSK_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define LSK_ELEM_DTYPE 1
+#else
+typedef __bf16 elem_t;
+typedef __bf16 elem8 __attribute__((ext_vector_type(8)));
+#define LSK_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define LSK_ELEM_DTYPE 0
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -16,11 +28,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LSK_SPW 16             // k-steps per wave per (tile, chunk) unit = depth of the weight ring
 #define LSK_ROWS 16
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
-__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }   // round-to-nearest-even
+__device__ __forceinline__ float e2f(elem_t v) { return (float)v; }
+__device__ __forceinline__ elem_t f2e(float v) { return (elem_t)v; }   // round-to-nearest-even
 // One rounding to the model dtype, result widened again (the reference rounds wherever HF's
 // bf16 modules materialise a tensor).
-__device__ __forceinline__ float rbf(float v) { return (float)((bf16_t)v); }
+__device__ __forceinline__ float rnd_e(float v) { return (float)((elem_t)v); }
 
 // Cross-lane traffic goes through DPP (VALU, a few cycles) instead of __shfl_xor, which hipcc lowers to
 // ds_bpermute_b32: an LDS-pipe round trip of ~100 cycles per step that sat 6-deep on every reduction of the
@@ -71,37 +83,37 @@ enum { PRO_PLAIN = 0, PRO_RMS = 1 };
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_HEAD = 4 };
 
 struct GemmParams {
-    const bf16_t* x;        // [M][ldx] input rows
+    const elem_t* x;        // [M][ldx] input rows
     int ldx;
     int M;                  // 1..16
     int K;                  // multiple of 32
-    const bf16_t* wp;       // packed weight tiles [n_tiles][K/32][64][8]
+    const elem_t* wp;       // packed weight tiles [n_tiles][K/32][64][8]
     unsigned wp_bytes;
     int N;                  // logical output features (rows of the nn.Linear weight)
     int n_tiles;            // ceil(N / 16)
     int tiles_per_wg;       // <= 8 (<= 16 for SWIGLU: 8 gate/up pairs)
-    const bf16_t* norm_w;   // PRO_RMS gain [K]
+    const elem_t* norm_w;   // PRO_RMS gain [K]
     float eps;
     // EPI_F32
     float* y;               // [M][N]
     // EPI_RESID: h[row][n] = bf16(h + bf16(acc))
-    bf16_t* h;
+    elem_t* h;
     int ldh;
     // EPI_SWIGLU: act[row][p*16+c]
-    bf16_t* act;
+    elem_t* act;
     int ldact;
     // EPI_QKV
-    bf16_t* q_out;          // [M][n_heads*head_dim]
+    elem_t* q_out;          // [M][n_heads*head_dim]
     int ldq;
-    bf16_t* kpool;          // this layer's K pages [page][n_kv][page_size][head_dim]
-    bf16_t* vpool;
+    elem_t* kpool;          // this layer's K pages [page][n_kv][page_size][head_dim]
+    elem_t* vpool;
     const int* block_table;
     int page_size;
     int n_heads;
     int n_kv;
     int head_dim;
-    const bf16_t* rope_cos; // [rope_len][head_dim/2]
-    const bf16_t* rope_sin;
+    const elem_t* rope_cos; // [rope_len][head_dim/2]
+    const elem_t* rope_sin;
     const int* kv_len;      // device scalar: verified context length C
     int pos_off;            // row i sits at position *kv_len + pos_off + i
     // EPI_HEAD

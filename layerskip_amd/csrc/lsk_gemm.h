@@ -64,14 +64,14 @@ __host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS
 // K-chunk into registers (issued before / under the weight stream), `lsk_store_chunk` applies the
 // RMSNorm (if any) and writes the bf16 rows to LDS later, without touching global memory.
 template <int PRO, int MB, bool COHERENT = false>
-__device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int steps_c, int tid, bf16x8 (&xr)[MB], bf16x8& nw) {
+__device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int steps_c, int tid, elem8 (&xr)[MB], elem8& nw) {
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
         const int k0 = c * LSK_KC_ELEMS + e0;
-        if (PRO == PRO_RMS) nw = *(const bf16x8*)(p.norm_w + k0);
+        if (PRO == PRO_RMS) nw = *(const elem8*)(p.norm_w + k0);
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
-            const bf16_t* src = p.x + (size_t)min(i, p.M - 1) * p.ldx + k0;
+            const elem_t* src = p.x + (size_t)min(i, p.M - 1) * p.ldx + k0;
             if (COHERENT) {
                 // rows published by another workgroup of the SAME launch with write-through stores: read them
                 // with agent-scope (sc1) loads, which bypass this CU's possibly stale L1 lines
@@ -79,9 +79,9 @@ __device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int s
                 unsigned long long hi = __hip_atomic_load((const unsigned long long*)src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
                 u64x2 v = {lo, hi};
-                xr[i] = __builtin_bit_cast(bf16x8, v);
+                xr[i] = __builtin_bit_cast(elem8, v);
             } else {
-                xr[i] = *(const bf16x8*)src;
+                xr[i] = *(const elem8*)src;
             }
         }
     }
@@ -89,22 +89,22 @@ __device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int s
 
 template <int PRO, int MB>
 __device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned char* xs, int xstride, const float (&sv)[MB],
-                                                int steps_c, int tid, const bf16x8 (&xr)[MB], const bf16x8& nw) {
+                                                int steps_c, int tid, const elem8 (&xr)[MB], const elem8& nw) {
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             if (i < p.M) {
-                bf16x8 v = xr[i];
+                elem8 v = xr[i];
                 if (PRO == PRO_RMS) {
                     const float s = sv[i];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float xn = rbf(bf2f(v[j]) * s);           // x32 * rsqrt(var + eps) -> model dtype
-                        v[j] = f2bf(bf2f(nw[j]) * xn);                   // weight * that, rounded again
+                        const float xn = rnd_e(e2f(v[j]) * s);           // x32 * rsqrt(var + eps) -> model dtype
+                        v[j] = f2e(e2f(nw[j]) * xn);                   // weight * that, rounded again
                     }
                 }
-                *(bf16x8*)(xs + (size_t)i * xstride + e0 * 2) = v;
+                *(elem8*)(xs + (size_t)i * xstride + e0 * 2) = v;
             }
         }
     }
@@ -162,7 +162,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
-                if (row < M && n < p.N) pre_a[i] = bf2f(p.h[(size_t)row * p.ldh + n]);
+                if (row < M && n < p.N) pre_a[i] = e2f(p.h[(size_t)row * p.ldh + n]);
             }
         }
     } else if (EPI == EPI_QKV) {
@@ -181,8 +181,8 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             for (int i = 0; i < 4; ++i) {
                 const int pos = base_pos + min(rg * 4 + i, M - 1);
                 if (kind != 2) {
-                    pre_a[i] = bf2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
-                    pre_b[i] = bf2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
+                    pre_a[i] = e2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
+                    pre_b[i] = e2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
                 }
                 if (kind != 0) pre_pg[i] = p.block_table[pos / p.page_size];
             }
@@ -191,8 +191,8 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 
     // ---- activations next (they must not queue behind the weight ring), then fill the ring ----
     UnitInfo cur = lsk_unit_info(0, units, ntl, ksteps, tile0, w, lane);
-    bf16x8 xr[MB];
-    bf16x8 nw;
+    elem8 xr[MB];
+    elem8 nw;
     float ss[MB];
     float sv[MB];                 // per-row 1/rms (PRO_RMS), wave-uniform
     u32x4 ring[LSK_SPW];
@@ -220,7 +220,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                 if (row < M && n < p.N) {
                     const unsigned short bits = __hip_atomic_load((const unsigned short*)(p.h + (size_t)row * p.ldh + n),
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pre_a[i] = bf2f(__builtin_bit_cast(bf16_t, bits));
+                    pre_a[i] = e2f(__builtin_bit_cast(elem_t, bits));
                 }
             }
         }
@@ -236,7 +236,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float f = bf2f(xr[i][j]); ss[i] = fmaf(f, f, ss[i]); }
+                    for (int j = 0; j < 8; ++j) { const float f = e2f(xr[i][j]); ss[i] = fmaf(f, f, ss[i]); }
             }
         }
     } else {
@@ -282,9 +282,9 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     // A wave owns the same k-steps of every tile of a K-chunk, so its 16 A fragments are read from LDS once per
     // chunk and stay in VGPRs: the unit loop then waits on the weight stream only (with a ds_read in front of
     // every MFMA the LDS latency was exposed ~8x per unit and the ring refills queued up behind it).
-    bf16x8 afr[LSK_SPW];
+    elem8 afr[LSK_SPW];
 #pragma unroll
-    for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const bf16x8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
+    for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const elem8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
 
     for (int u = 0; u < units; ++u) {
         const UnitInfo nxt = lsk_unit_info(u + 1, units, ntl, ksteps, tile0, w, lane);
@@ -296,12 +296,12 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                 lsk_load_chunk<PRO, MB, WAIT>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
             __syncthreads();
 #pragma unroll
-            for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const bf16x8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
+            for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const elem8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < LSK_SPW; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[s], __builtin_bit_cast(bf16x8, ring[s]), acc, 0, 0, 0);
+            acc = LSK_MFMA_16x16x32(afr[s], __builtin_bit_cast(elem8, ring[s]), acc, 0, 0, 0);
             const unsigned off = (s < nxt.nvalid) ? nxt.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
             ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
             // (hipcc sinks these refills into bursts behind later MFMAs, so the ring runs ~8-16 deep; pinning
@@ -340,7 +340,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
                 if (row < M && n < p.N) {
-                    const bf16_t r = f2bf(pre_a[i] + rbf(own0[i]));                 // residual + Linear(...) in model dtype
+                    const elem_t r = f2e(pre_a[i] + rnd_e(own0[i]));                 // residual + Linear(...) in model dtype
                     if (PUBLISH) __hip_atomic_store((unsigned short*)(p.h + (size_t)row * p.ldh + n), __builtin_bit_cast(unsigned short, r),
                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
                     else p.h[(size_t)row * p.ldh + n] = r;
@@ -354,10 +354,10 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
                 if (row < M && n < (p.N >> 1)) {
-                    const float g = rbf(own0[i]);                    // gate_proj(x)
-                    const float uu = rbf(own1[i]);                   // up_proj(x)
-                    const float s = rbf(g / (1.0f + expf(-g)));      // silu in fp32, one rounding
-                    const bf16_t r = f2bf(s * uu);
+                    const float g = rnd_e(own0[i]);                    // gate_proj(x)
+                    const float uu = rnd_e(own1[i]);                   // up_proj(x)
+                    const float s = rnd_e(g / (1.0f + expf(-g)));      // silu in fp32, one rounding
+                    const elem_t r = f2e(s * uu);
                     if (PUBLISH) __hip_atomic_store((unsigned short*)(p.act + (size_t)row * p.ldact + n), __builtin_bit_cast(unsigned short, r),
                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
                     else p.act[(size_t)row * p.ldact + n] = r;
@@ -379,29 +379,29 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
                 const int pos = base_pos + min(row, M - 1);
-                float v = rbf(own0[i]);
+                float v = rnd_e(own0[i]);
                 int feat;
                 if (kind != 2) {
                     const float partner = row_xor8(v);
                     const int j = tt * 8 + (c16 & 7);
                     const float cs = pre_a[i];
                     const float sn = pre_b[i];
-                    const float a = rbf(v * cs);                               // q * cos
-                    const float b = rbf((c16 < 8 ? -partner : partner) * sn);  // rotate_half(q) * sin
-                    v = rbf(a + b);
+                    const float a = rnd_e(v * cs);                               // q * cos
+                    const float b = rnd_e((c16 < 8 ? -partner : partner) * sn);  // rotate_half(q) * sin
+                    v = rnd_e(a + b);
                     feat = (c16 < 8) ? j : j + (hd >> 1);
                 } else {
                     feat = tt * 16 + c16;
                 }
                 if (row < M) {
                     if (kind == 0) {
-                        p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2bf(v);
+                        p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2e(v);
                     } else {
                         const int page = pre_pg[i];
                         const int slot = pos % p.page_size;
                         const size_t hb = ((size_t)page * p.n_kv + head) * p.page_size * hd;
-                        if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2bf(v);        // K page  [slot][d]
-                        else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2bf(v);         // V^T page [d][slot]
+                        if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2e(v);        // K page  [slot][d]
+                        else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2e(v);         // V^T page [d][slot]
                     }
                 }
             }
@@ -414,7 +414,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
-                float v = rbf(own0[i]);                              // logits in model dtype
+                float v = rnd_e(own0[i]);                              // logits in model dtype
                 if (p.logits != nullptr && row < M && n < p.N) p.logits[(size_t)row * p.ld_logits + n] = v;
                 int idx = n;
                 if (n >= p.N) { v = -INFINITY; idx = 0x7fffffff; }

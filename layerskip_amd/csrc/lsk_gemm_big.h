@@ -20,31 +20,31 @@
 #define LSK_BIG_LDA 160          // bytes per LDS row: 64 bf16 + 32 B pad (slot (10r + g) mod 16: conflict-free A-fragment reads)
 
 struct BigGemmParams {
-    const bf16_t* x;        // [M][ldx]
+    const elem_t* x;        // [M][ldx]
     int ldx;
     int M;
     int K;                  // multiple of 64
-    const bf16_t* wp;       // packed tiles
+    const elem_t* wp;       // packed tiles
     int N;
     int n_tiles;
     // EPI_RESID
-    bf16_t* h;
+    elem_t* h;
     int ldh;
     // EPI_SWIGLU
-    bf16_t* act;
+    elem_t* act;
     int ldact;
     // EPI_QKV
-    bf16_t* q_out;
+    elem_t* q_out;
     int ldq;
-    bf16_t* kpool;
-    bf16_t* vpool;
+    elem_t* kpool;
+    elem_t* vpool;
     const int* block_table;
     int page_size;
     int n_heads;
     int n_kv;
     int head_dim;
-    const bf16_t* rope_cos;
-    const bf16_t* rope_sin;
+    const elem_t* rope_cos;
+    const elem_t* rope_sin;
     const int* kv_len;
     int pos_off;
 };
@@ -68,11 +68,11 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
     const int arow = tid >> 1;
     const int ahalf = tid & 1;
     const int grow = min(m0 + arow, p.M - 1);
-    const bf16_t* aptr = p.x + (size_t)grow * p.ldx + ahalf * 32;
+    const elem_t* aptr = p.x + (size_t)grow * p.ldx + ahalf * 32;
     unsigned char* awr = lds + arow * LSK_BIG_LDA + ahalf * 64;
     // B fragments: packed tile T, k-step s at ((T*ksteps + s)*64 + lane)*8 elements
-    const bf16_t* bptr0 = p.wp + ((size_t)T0 * ksteps * 64 + lane) * 8;
-    const bf16_t* bptr1 = bptr0 + (size_t)ksteps * 512;
+    const elem_t* bptr0 = p.wp + ((size_t)T0 * ksteps * 64 + lane) * 8;
+    const elem_t* bptr1 = bptr0 + (size_t)ksteps * 512;
 
     f32x4 acc[8][2];
 #pragma unroll
@@ -80,18 +80,18 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 areg[4];
-    bf16x8 bcur[2][2], bnxt[2][2];
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    elem8 areg[4];
+    elem8 bcur[2][2], bnxt[2][2];
+    const elem8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) areg[i] = *(const bf16x8*)(aptr + i * 8);
+    for (int i = 0; i < 4; ++i) areg[i] = *(const elem8*)(aptr + i * 8);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        bcur[0][s] = tile_ok ? *(const bf16x8*)(bptr0 + (size_t)s * 512) : zero8;
-        bcur[1][s] = tile1_ok ? *(const bf16x8*)(bptr1 + (size_t)s * 512) : zero8;
+        bcur[0][s] = tile_ok ? *(const elem8*)(bptr0 + (size_t)s * 512) : zero8;
+        bcur[1][s] = tile1_ok ? *(const elem8*)(bptr1 + (size_t)s * 512) : zero8;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(bf16x8*)(awr + i * 16) = areg[i];
+    for (int i = 0; i < 4; ++i) *(elem8*)(awr + i * 16) = areg[i];
     __syncthreads();
 
     const unsigned char* ard = lds + (lane & 15) * LSK_BIG_LDA + (lane >> 4) * 16;
@@ -99,14 +99,14 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
         if (more) {
-            const bf16_t* an = aptr + (size_t)(kt + 1) * LSK_BIG_BK;
+            const elem_t* an = aptr + (size_t)(kt + 1) * LSK_BIG_BK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) areg[i] = *(const bf16x8*)(an + i * 8);
+            for (int i = 0; i < 4; ++i) areg[i] = *(const elem8*)(an + i * 8);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const size_t bo = (size_t)((kt + 1) * 2 + s) * 512;
-                bnxt[0][s] = tile_ok ? *(const bf16x8*)(bptr0 + bo) : zero8;
-                bnxt[1][s] = tile1_ok ? *(const bf16x8*)(bptr1 + bo) : zero8;
+                bnxt[0][s] = tile_ok ? *(const elem8*)(bptr0 + bo) : zero8;
+                bnxt[1][s] = tile1_ok ? *(const elem8*)(bptr1 + bo) : zero8;
             }
         }
         const unsigned char* abase = ard + cur * (LSK_BIG_BM * LSK_BIG_LDA);
@@ -114,15 +114,15 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
-                const bf16x8 a = *(const bf16x8*)(abase + mt * 16 * LSK_BIG_LDA + s * 64);
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[0][s], acc[mt][0], 0, 0, 0);
-                if (NTW == 2) acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[1][s], acc[mt][1], 0, 0, 0);
+                const elem8 a = *(const elem8*)(abase + mt * 16 * LSK_BIG_LDA + s * 64);
+                acc[mt][0] = LSK_MFMA_16x16x32(a, bcur[0][s], acc[mt][0], 0, 0, 0);
+                if (NTW == 2) acc[mt][1] = LSK_MFMA_16x16x32(a, bcur[1][s], acc[mt][1], 0, 0, 0);
             }
         }
         if (more) {
             unsigned char* dst = awr + (cur ^ 1) * (LSK_BIG_BM * LSK_BIG_LDA);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *(bf16x8*)(dst + i * 16) = areg[i];
+            for (int i = 0; i < 4; ++i) *(elem8*)(dst + i * 16) = areg[i];
 #pragma unroll
             for (int s = 0; s < 2; ++s) { bcur[0][s] = bnxt[0][s]; bcur[1][s] = bnxt[1][s]; }
         }
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
                 for (int i = 0; i < 4; ++i) {
                     const int row = m0 + mt * 16 + rg * 4 + i;
                     if (row < p.M && n < p.N) {
-                        bf16_t* hp = p.h + (size_t)row * p.ldh + n;
-                        *hp = f2bf(bf2f(*hp) + rbf(acc[mt][nt][i]));
+                        elem_t* hp = p.h + (size_t)row * p.ldh + n;
+                        *hp = f2e(e2f(*hp) + rnd_e(acc[mt][nt][i]));
                     }
                 }
         }
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
             for (int i = 0; i < 4; ++i) {
                 const int row = m0 + mt * 16 + rg * 4 + i;
                 if (row < p.M && n < (p.N >> 1)) {
-                    const float g = rbf(acc[mt][0][i]);
-                    const float uu = rbf(acc[mt][1][i]);
-                    const float s = rbf(g / (1.0f + expf(-g)));
-                    p.act[(size_t)row * p.ldact + n] = f2bf(s * uu);
+                    const float g = rnd_e(acc[mt][0][i]);
+                    const float uu = rnd_e(acc[mt][1][i]);
+                    const float s = rnd_e(g / (1.0f + expf(-g)));
+                    p.act[(size_t)row * p.ldact + n] = f2e(s * uu);
                 }
             }
     } else if (EPI == EPI_QKV) {
@@ -181,29 +181,29 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
                 for (int i = 0; i < 4; ++i) {
                     const int row = m0 + mt * 16 + rg * 4 + i;
                     const int pos = base_pos + min(row, p.M - 1);
-                    float v = rbf(acc[mt][nt][i]);
+                    float v = rnd_e(acc[mt][nt][i]);
                     int feat;
                     if (kind != 2) {
                         const float partner = row_xor8(v);
                         const int j = tt * 8 + (c16 & 7);
-                        const float cs = bf2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
-                        const float sn = bf2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
-                        const float a = rbf(v * cs);
-                        const float b = rbf((c16 < 8 ? -partner : partner) * sn);
-                        v = rbf(a + b);
+                        const float cs = e2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
+                        const float sn = e2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
+                        const float a = rnd_e(v * cs);
+                        const float b = rnd_e((c16 < 8 ? -partner : partner) * sn);
+                        v = rnd_e(a + b);
                         feat = (c16 < 8) ? j : j + (hd >> 1);
                     } else {
                         feat = tt * 16 + c16;
                     }
                     if (row < p.M) {
                         if (kind == 0) {
-                            p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2bf(v);
+                            p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2e(v);
                         } else {
                             const int page = p.block_table[pos / p.page_size];
                             const int slot = pos % p.page_size;
                             const size_t hb = ((size_t)page * p.n_kv + head) * p.page_size * hd;
-                            if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2bf(v);        // K page  [slot][d]
-                            else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2bf(v);         // V^T page [d][slot]
+                            if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2e(v);        // K page  [slot][d]
+                            else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2e(v);         // V^T page [d][slot]
                         }
                     }
                 }
@@ -212,27 +212,27 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
 }
 
 // xn[row] = weight * bf16(x * rsqrt(mean(x^2) + eps))   (LlamaRMSNorm, modeling_llama.py:62-67), one row per workgroup
-__global__ __launch_bounds__(256) void lsk_rmsnorm_rows_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w,
-                                                               float eps, int K, bf16_t* __restrict__ y, int ldy) {
+__global__ __launch_bounds__(256) void lsk_rmsnorm_rows_kernel(const elem_t* __restrict__ x, int ldx, const elem_t* __restrict__ w,
+                                                               float eps, int K, elem_t* __restrict__ y, int ldy) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     const int tid = threadIdx.x;
-    const bf16_t* xr = x + (size_t)row * ldx;
+    const elem_t* xr = x + (size_t)row * ldx;
     float ss = 0.f;
     for (int k0 = tid * 8; k0 < K; k0 += 256 * 8) {
-        const bf16x8 v = *(const bf16x8*)(xr + k0);
+        const elem8 v = *(const elem8*)(xr + k0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss = fmaf(f, f, ss); }
+        for (int j = 0; j < 8; ++j) { const float f = e2f(v[j]); ss = fmaf(f, f, ss); }
     }
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
     const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
     for (int k0 = tid * 8; k0 < K; k0 += 256 * 8) {
-        bf16x8 v = *(const bf16x8*)(xr + k0);
-        const bf16x8 g = *(const bf16x8*)(w + k0);
+        elem8 v = *(const elem8*)(xr + k0);
+        const elem8 g = *(const elem8*)(w + k0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(g[j]) * rbf(bf2f(v[j]) * inv));
-        *(bf16x8*)(y + (size_t)row * ldy + k0) = v;
+        for (int j = 0; j < 8; ++j) v[j] = f2e(e2f(g[j]) * rnd_e(e2f(v[j]) * inv));
+        *(elem8*)(y + (size_t)row * ldy + k0) = v;
     }
 }

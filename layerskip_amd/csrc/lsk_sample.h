@@ -41,9 +41,9 @@ struct SampleParams {
     int tag0;                   // RNG row tag of row 0 (row r uses tag0 + r)
     int* tokens_out;            // [m]
     float* probs_out;           // [m][ld]
-    const bf16_t* embed;        // optional: embedding table, to place the sampled token of row 0 in the next draft row
+    const elem_t* embed;        // optional: embedding table, to place the sampled token of row 0 in the next draft row
     int hidden;
-    bf16_t* embed_dst;
+    elem_t* embed_dst;
 };
 
 __host__ __device__ inline void lsk_philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_kernel(const Sa
     const int tok = block_argmax(best, best_i, red, redi);
     if (tid == 0) p.tokens_out[row] = tok;
     if (row == 0 && p.embed_dst != nullptr) {
-        const bf16x8* src = (const bf16x8*)(p.embed + (size_t)tok * p.hidden);
-        bf16x8* dst = (bf16x8*)p.embed_dst;
+        const elem8* src = (const elem8*)(p.embed + (size_t)tok * p.hidden);
+        elem8* dst = (elem8*)p.embed_dst;
         for (int i = tid; i < p.hidden / 8; i += LSK_SAMPLE_THREADS) dst[i] = src[i];
     }
 }

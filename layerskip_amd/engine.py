@@ -11,13 +11,14 @@ PyTorch is used for storage and stream handles only: every tensor here is a buff
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 import torch
 
 from . import _lib
-from ._lib import LskConfig, LskStepResult, check
+from ._lib import LskConfig, LskStepResult
 
 BUF_STEP = 0   # 16-row step buffer (draft rows / verify block)
 BUF_BULK = 1   # prompt rows (prefill), doubles as the exit_query_cache of the first step
@@ -49,6 +50,9 @@ def _i32_array(values: Sequence[int]):
 class HipEngine:
     """One engine per (model, device).  Not re-entrant; one caller thread (like the reference)."""
 
+    def _ck(self, status: int) -> None:
+        _lib.check(status, self.lib)
+
     def _eos_array(self, eos_token_ids: Sequence[int]):
         """Ids outside the vocabulary can never be produced and are dropped; more than LSK_MAX_EOS real ids is an
         error (never a silent truncation: the device-side draft cut and the host-side output cut must agree)."""
@@ -59,13 +63,22 @@ class HipEngine:
 
     def __init__(self, model, max_ctx: int = 2048, max_prompt: int = 1024, page_size: int = 128,
                  target_wgs: int = 0, layer_range: Optional[Sequence[int]] = None, release_weights: bool = False):
-        self.lib = _lib.load()
         cfg = model.config
         weight = model.model.embed_tokens.weight
         if weight.device.type != "cuda":
             raise _lib.LskError("HipEngine needs the model on a HIP device (model.to('cuda')); there is no CPU path")
-        if weight.dtype != torch.bfloat16:
-            raise _lib.LskError(f"HipEngine computes in bf16; model dtype is {weight.dtype}")
+        if weight.dtype == torch.bfloat16:
+            self.dtype, dtype_name = torch.bfloat16, "bf16"
+        elif weight.dtype == torch.float16:
+            # the fp16 library is the same sources built with -DLSK_ELEM_F16; it has not been run on hardware yet
+            # (written after round 1's GPU budget was spent), so it must be asked for explicitly
+            if os.environ.get("LSK_EXPERIMENTAL") != "1":
+                raise _lib.LskError("the fp16 engine is experimental in this round: set LSK_EXPERIMENTAL=1 to use it, "
+                                    "or load the model in bf16 (torch_dtype=torch.bfloat16)")
+            self.dtype, dtype_name = torch.float16, "fp16"
+        else:
+            raise _lib.LskError(f"HipEngine computes in bf16 (or fp16); model dtype is {weight.dtype}")
+        self.lib = _lib.load(dtype=dtype_name)
         if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
             raise _lib.LskError("biased projections are not supported")
         # The engine keeps its own references to every tensor it borrows (embedding, norm gains) and copies of the
@@ -112,16 +125,16 @@ class HipEngine:
 
     def _packed_buffer(self, n_rows: int, k: int) -> torch.Tensor:
         nbytes = ctypes.c_size_t(0)
-        check(self.lib.lsk_packed_bytes(n_rows, k, ctypes.byref(nbytes)))
+        self._ck(self.lib.lsk_packed_bytes(n_rows, k, ctypes.byref(nbytes)))
         return torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
 
     def _pack_into(self, dst: torch.Tensor, w: torch.Tensor, tile_offset: int, tile_stride: int, rope_hd: int) -> None:
         w = w.detach()
-        if w.dtype != torch.bfloat16 or w.device != self.device:
-            raise _lib.LskError("all projection weights must be bf16 on the engine's device")
+        if w.dtype != self.dtype or w.device != self.device:
+            raise _lib.LskError(f"all projection weights must be {self.dtype} on the engine's device")
         if w.stride(1) != 1:
             w = w.contiguous()
-        check(self.lib.lsk_pack_linear(w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), dst.data_ptr(),
+        self._ck(self.lib.lsk_pack_linear(w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), dst.data_ptr(),
                                        tile_offset, tile_stride, rope_hd, self._stream))
 
     def _pack_weights(self, m) -> None:
@@ -149,7 +162,7 @@ class HipEngine:
             if self.release_weights:
                 torch.cuda.synchronize(self.device)
                 for lin in (a.q_proj, a.k_proj, a.v_proj, a.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
-                    lin.weight = torch.nn.Parameter(torch.empty(0, dtype=torch.bfloat16, device=self.device),
+                    lin.weight = torch.nn.Parameter(torch.empty(0, dtype=self.dtype, device=self.device),
                                                     requires_grad=False)
         head = self._packed_buffer(self.vocab, H)
         self._pack_into(head, m.lm_head.weight, 0, 1, 0)
@@ -157,25 +170,25 @@ class HipEngine:
         tied = m.lm_head.weight.data_ptr() == m.model.embed_tokens.weight.data_ptr()
         if self.release_weights and not tied:
             torch.cuda.synchronize(self.device)
-            m.lm_head.weight = torch.nn.Parameter(torch.empty(0, dtype=torch.bfloat16, device=self.device),
+            m.lm_head.weight = torch.nn.Parameter(torch.empty(0, dtype=self.dtype, device=self.device),
                                                   requires_grad=False)
         self._globals["embed"] = m.model.embed_tokens.weight.detach().contiguous()
         self._globals["final_norm"] = m.model.norm.weight.detach().contiguous()
         torch.cuda.synchronize(self.device)
 
     def _rope_tables(self, length: int):
-        """cos/sin exactly as LlamaRotaryEmbedding.forward computes them on CPU (fp32 -> bf16)."""
+        """cos/sin exactly as LlamaRotaryEmbedding.forward computes them on CPU (fp32 -> model dtype)."""
         inv_freq, scaling = self._inv_freq, self._rope_scaling
         pos = torch.arange(length, dtype=torch.float32)
         freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]   # [length, d/2]
-        cos = (freqs.cos() * scaling).to(torch.bfloat16)
-        sin = (freqs.sin() * scaling).to(torch.bfloat16)
+        cos = (freqs.cos() * scaling).to(self.dtype)
+        sin = (freqs.sin() * scaling).to(self.dtype)
         return cos.contiguous().to(self.device), sin.contiguous().to(self.device)
 
     # ------------------------------------------------------------------ buffers / C engine
     def _allocate(self, max_ctx: int, max_prompt: int) -> None:
         if self._handle:
-            check(self.lib.lsk_engine_destroy(self._handle))
+            self._ck(self.lib.lsk_engine_destroy(self._handle))
             self._handle = ctypes.c_void_p(None)
         self.max_ctx = _round_up(max(max_ctx, self.page_size), self.page_size)
         self.max_prompt = max(16, int(max_prompt))
@@ -183,8 +196,8 @@ class HipEngine:
                              self.head_dim, self.vocab, self.rms_eps, self.max_ctx, self.page_size,
                              self.max_prompt, self.target_wgs)
         ws, kv = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        check(self.lib.lsk_workspace_bytes(ctypes.byref(self.cfg), ctypes.byref(ws)))
-        check(self.lib.lsk_kv_pool_bytes(ctypes.byref(self.cfg), ctypes.byref(kv)))
+        self._ck(self.lib.lsk_workspace_bytes(ctypes.byref(self.cfg), ctypes.byref(ws)))
+        self._ck(self.lib.lsk_kv_pool_bytes(ctypes.byref(self.cfg), ctypes.byref(kv)))
         self._buffers.pop("sampling", None)
         self._buffers["ws"] = torch.zeros(ws.value, dtype=torch.uint8, device=self.device)
         self._buffers["kv"] = torch.zeros(kv.value, dtype=torch.uint8, device=self.device)
@@ -192,17 +205,17 @@ class HipEngine:
         self._buffers["cos"], self._buffers["sin"] = cos, sin
         torch.cuda.synchronize(self.device)
         handle = ctypes.c_void_p(None)
-        check(self.lib.lsk_engine_create(ctypes.byref(self.cfg), self._buffers["ws"].data_ptr(), ws.value,
+        self._ck(self.lib.lsk_engine_create(ctypes.byref(self.cfg), self._buffers["ws"].data_ptr(), ws.value,
                                          self._buffers["kv"].data_ptr(), kv.value, ctypes.byref(handle)))
         self._handle = handle
         for i, packed in enumerate(self._packed):
             if packed is None:
                 continue
             wqkv, wo, wgu, wdown, n1, n2 = packed
-            check(self.lib.lsk_engine_set_layer(handle, i, wqkv.data_ptr(), wo.data_ptr(), wgu.data_ptr(),
+            self._ck(self.lib.lsk_engine_set_layer(handle, i, wqkv.data_ptr(), wo.data_ptr(), wgu.data_ptr(),
                                                 wdown.data_ptr(), n1.data_ptr(), n2.data_ptr()))
         g = self._globals
-        check(self.lib.lsk_engine_set_globals(handle, g["embed"].data_ptr(), g["final_norm"].data_ptr(),
+        self._ck(self.lib.lsk_engine_set_globals(handle, g["embed"].data_ptr(), g["final_norm"].data_ptr(),
                                               g["lm_head"].data_ptr(), cos.data_ptr(), sin.data_ptr(), self.max_ctx))
 
     def ensure_capacity(self, total_tokens: int, prompt_len: int) -> None:
@@ -224,20 +237,20 @@ class HipEngine:
 
     # ------------------------------------------------------------------ state
     def reset(self) -> None:
-        check(self.lib.lsk_engine_reset(self._handle, self._stream))
+        self._ck(self.lib.lsk_engine_reset(self._handle, self._stream))
 
     @property
     def kv_len(self) -> int:
         v = ctypes.c_int32(0)
-        check(self.lib.lsk_engine_get_kv_len(self._handle, ctypes.byref(v)))
+        self._ck(self.lib.lsk_engine_get_kv_len(self._handle, ctypes.byref(v)))
         return v.value
 
     def set_kv_len(self, kv_len: int) -> None:
-        check(self.lib.lsk_engine_set_kv_len(self._handle, int(kv_len), self._stream))
+        self._ck(self.lib.lsk_engine_set_kv_len(self._handle, int(kv_len), self._stream))
 
     def set_block_table(self, table: Sequence[int]) -> None:
         arr = _i32_array(table)
-        check(self.lib.lsk_engine_set_block_table(self._handle, arr, len(table), self._stream))
+        self._ck(self.lib.lsk_engine_set_block_table(self._handle, arr, len(table), self._stream))
 
     # ------------------------------------------------------------------ fused fast paths
     def spec_step(self, input_ids: Sequence[int], num_speculations: int, exit_layer: int,
@@ -245,7 +258,7 @@ class HipEngine:
         ids = _i32_array(input_ids)
         eos, eos_arr = self._eos_array(eos_token_ids)
         res = LskStepResult()
-        check(self.lib.lsk_spec_step(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer),
+        self._ck(self.lib.lsk_spec_step(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer),
                                      eos_arr, len(eos), ctypes.byref(res), self._stream))
         n, s = res.num_matches, int(num_speculations)
         return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
@@ -260,7 +273,7 @@ class HipEngine:
         sd = (ctypes.c_int32 * max_steps)()
         sm = (ctypes.c_int32 * max_steps)()
         n_out, tm, td, ns = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
-        check(self.lib.lsk_spec_generate(self._handle, ids, len(prompt_ids), int(num_speculations), int(exit_layer), eos_arr,
+        self._ck(self.lib.lsk_spec_generate(self._handle, ids, len(prompt_ids), int(num_speculations), int(exit_layer), eos_arr,
                                          len(eos), int(max_steps), out, ctypes.byref(n_out), ctypes.byref(tm), ctypes.byref(td),
                                          sd, sm, ctypes.byref(ns), self._stream))
         steps = [(sd[i], sm[i]) for i in range(ns.value)]
@@ -271,7 +284,7 @@ class HipEngine:
         buf = self._buffers.get("sampling")
         if buf is None:
             n = ctypes.c_size_t(0)
-            check(self.lib.lsk_sampling_scratch_bytes(ctypes.byref(self.cfg), ctypes.byref(n)))
+            self._ck(self.lib.lsk_sampling_scratch_bytes(ctypes.byref(self.cfg), ctypes.byref(n)))
             buf = torch.empty(n.value, dtype=torch.uint8, device=self.device)
             self._buffers["sampling"] = buf
         return buf
@@ -285,7 +298,7 @@ class HipEngine:
         m, ld = logits.shape[0], logits.stride(0)
         toks = torch.empty(m, dtype=torch.int32, device=self.device)
         probs = torch.empty(m, ld, dtype=torch.float32, device=self.device)
-        check(self.lib.lsk_sample_rows(self._handle, logits.data_ptr(), ld, m, float(temperature), int(top_k), float(top_p),
+        self._ck(self.lib.lsk_sample_rows(self._handle, logits.data_ptr(), ld, m, float(temperature), int(top_k), float(top_p),
                                        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(tag0), toks.data_ptr(),
                                        probs.data_ptr(), self._stream))
         return toks, probs
@@ -298,7 +311,7 @@ class HipEngine:
         eos, eos_arr = self._eos_array(eos_token_ids)
         res = LskStepResult()
         scratch = self._sampling_scratch()
-        check(self.lib.lsk_spec_step_sampled(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer), eos_arr,
+        self._ck(self.lib.lsk_spec_step_sampled(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer), eos_arr,
                                              len(eos), float(temperature), int(top_k), float(top_p), int(seed) & (2 ** 64 - 1),
                                              int(offset) & (2 ** 64 - 1), scratch.data_ptr(), scratch.numel(), ctypes.byref(res),
                                              self._stream))
@@ -313,24 +326,24 @@ class HipEngine:
         eos, eos_arr = self._eos_array(eos_token_ids)
         out = (ctypes.c_int32 * max_steps)()
         n_out = ctypes.c_int32(0)
-        check(self.lib.lsk_ar_generate(self._handle, ids, len(input_ids), int(layer_end or self.num_layers), eos_arr,
+        self._ck(self.lib.lsk_ar_generate(self._handle, ids, len(input_ids), int(layer_end or self.num_layers), eos_arr,
                                        len(eos), int(max_steps), out, ctypes.byref(n_out), self._stream))
         return list(out[: n_out.value])
 
     def ar_step(self, input_ids: Sequence[int], layer_end: Optional[int] = None) -> int:
         ids = _i32_array(input_ids)
         tok = ctypes.c_int32(0)
-        check(self.lib.lsk_ar_step(self._handle, ids, len(input_ids), int(layer_end or self.num_layers),
+        self._ck(self.lib.lsk_ar_step(self._handle, ids, len(input_ids), int(layer_end or self.num_layers),
                                    ctypes.byref(tok), self._stream))
         return tok.value
 
     # ------------------------------------------------------------------ building blocks
     def embed_rows(self, ids: Sequence[int], buffer: int, row_base: int) -> None:
         arr = _i32_array(ids)
-        check(self.lib.lsk_embed_rows(self._handle, arr, len(ids), buffer, row_base, self._stream))
+        self._ck(self.lib.lsk_embed_rows(self._handle, arr, len(ids), buffer, row_base, self._stream))
 
     def run_layers(self, buffer: int, row_base: int, m: int, pos_offset: int, layer_begin: int, layer_end: int) -> None:
-        check(self.lib.lsk_run_layers(self._handle, buffer, row_base, m, pos_offset, layer_begin, layer_end, self._stream))
+        self._ck(self.lib.lsk_run_layers(self._handle, buffer, row_base, m, pos_offset, layer_begin, layer_end, self._stream))
 
     def run_layers_chunked(self, buffer: int, row_base: int, n: int, pos_offset: int, layer_begin: int, layer_end: int) -> None:
         for r0 in range(0, n, _lib.LSK_MAX_ROWS):
@@ -338,10 +351,10 @@ class HipEngine:
             self.run_layers(buffer, row_base + r0, m, pos_offset + r0, layer_begin, layer_end)
 
     def run_bulk(self, n: int, layer_begin: int, layer_end: int) -> None:
-        check(self.lib.lsk_run_bulk(self._handle, n, layer_begin, layer_end, self._stream))
+        self._ck(self.lib.lsk_run_bulk(self._handle, n, layer_begin, layer_end, self._stream))
 
     def set_option(self, option: int, value: int) -> None:
-        check(self.lib.lsk_engine_set_option(self._handle, option, value))
+        self._ck(self.lib.lsk_engine_set_option(self._handle, option, value))
 
     def run_head(self, buffer: int, row_base: int, m: int, logits: Optional[torch.Tensor] = None,
                  want_tokens: bool = True) -> Optional[List[int]]:
@@ -352,31 +365,31 @@ class HipEngine:
                 raise _lib.LskError("logits buffer must be a contiguous fp32 tensor on the engine device")
             ptr, ld = logits.data_ptr(), logits.stride(0)
         toks = (ctypes.c_int32 * m)() if want_tokens else None
-        check(self.lib.lsk_run_head(self._handle, buffer, row_base, m, ptr, ld, toks, self._stream))
+        self._ck(self.lib.lsk_run_head(self._handle, buffer, row_base, m, ptr, ld, toks, self._stream))
         return list(toks) if want_tokens else None
 
     def read_rows(self, buffer: int, row_base: int, m: int) -> torch.Tensor:
-        out = torch.empty(m, self.hidden, dtype=torch.bfloat16, device=self.device)
-        check(self.lib.lsk_read_rows(self._handle, buffer, row_base, m, out.data_ptr(), self._stream))
+        out = torch.empty(m, self.hidden, dtype=self.dtype, device=self.device)
+        self._ck(self.lib.lsk_read_rows(self._handle, buffer, row_base, m, out.data_ptr(), self._stream))
         return out
 
     def write_rows(self, buffer: int, row_base: int, rows: torch.Tensor) -> None:
-        rows = rows.to(self.device, torch.bfloat16).contiguous()
-        check(self.lib.lsk_write_rows(self._handle, buffer, row_base, rows.shape[0], rows.data_ptr(), self._stream))
+        rows = rows.to(self.device, self.dtype).contiguous()
+        self._ck(self.lib.lsk_write_rows(self._handle, buffer, row_base, rows.shape[0], rows.data_ptr(), self._stream))
 
     # ------------------------------------------------------------------ measurement hooks
     def time_gateup(self, layer: int, m: int, iters: int) -> float:
         ms = ctypes.c_float(0.0)
-        check(self.lib.lsk_time_gateup(self._handle, layer, m, iters, ctypes.byref(ms), self._stream))
+        self._ck(self.lib.lsk_time_gateup(self._handle, layer, m, iters, ctypes.byref(ms), self._stream))
         return ms.value
 
     def set_profile(self, enable: bool) -> None:
-        check(self.lib.lsk_engine_set_profile(self._handle, 1 if enable else 0))
+        self._ck(self.lib.lsk_engine_set_profile(self._handle, 1 if enable else 0))
 
     def get_profile(self):
         """(sum of the gate/up dispatch durations in ms, number of launches)."""
         ms, n = ctypes.c_float(0.0), ctypes.c_int32(0)
-        check(self.lib.lsk_engine_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n)))
+        self._ck(self.lib.lsk_engine_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
     # bytes one launch of each projection streams from HBM (algorithmic: the packed weights once)

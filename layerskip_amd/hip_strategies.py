@@ -186,7 +186,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         return next_input, output_ids, EngineCache(engine), n, step.num_drafts
 
     # ------------------------------------------------------------------------------ slow path
-    def _logits_rows(self, engine: HipEngine, rows: Sequence[Tuple[int, int, int]], dtype=torch.bfloat16) -> torch.Tensor:
+    def _logits_rows(self, engine: HipEngine, rows: Sequence[Tuple[int, int, int]], dtype=None) -> torch.Tensor:
         """Final-norm + lm_head logits of the listed (buffer, row_base, count) blocks -> [1, M, V]."""
         total = sum(c for _, _, c in rows)
         out = torch.empty(total, engine.vocab, dtype=torch.float32, device=engine.device)
@@ -196,7 +196,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                 m = min(_lib.LSK_MAX_ROWS, count - r0)
                 engine.run_head(buf, base + r0, m, logits=out[at:at + m], want_tokens=False)
                 at += m
-        return out.to(dtype).unsqueeze(0)
+        return out.to(dtype or getattr(engine, "dtype", torch.bfloat16)).unsqueeze(0)
 
     def _slow_step(self, engine: HipEngine, ids: List[int], spec: int, exit_layer: int, eos: List[int], sample: bool,
                    temperature: float, top_k: int, top_p: float, processors):

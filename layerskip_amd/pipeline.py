@@ -103,7 +103,7 @@ class PipelineSpeculativeDecoder:
     def _rows_in(self, buffer: int, row_base: int, m: int, src: int) -> None:
         for r0 in range(0, m, 256):
             k = min(256, m - r0)
-            self.be.write_rows(buffer, row_base + r0, self._recv((k, self.be.hidden), torch.bfloat16, src))
+            self.be.write_rows(buffer, row_base + r0, self._recv((k, self.be.hidden), getattr(self.be, "dtype", torch.bfloat16), src))
 
     # ------------------------------------------------------------------ one speculation step
     def _step(self, ids: Optional[List[int]], spec: int, eos: Sequence[int]):

@@ -22,6 +22,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.lsk_abi_version() == _lib.LSK_ABI_VERSION
+    assert lib.lsk_elem_dtype() == 0
+    # the fp16 build of the same sources exports the same boundary
+    lib16 = _lib.load(dtype="fp16")
+    for name in declared:
+        assert hasattr(lib16, name), name
+    assert lib16.lsk_elem_dtype() == 1 and lib16.lsk_abi_version() == _lib.LSK_ABI_VERSION
+    assert lib16 is not lib
 
 
 def test_size_queries_need_no_gpu():
@@ -66,3 +73,17 @@ def test_engine_refuses_cpu_models():
     with pytest.raises(_lib.LskError):
         HipEngine(model)
     assert not torch.cuda.is_available() or True
+
+
+def test_error_messages_come_from_the_library_that_failed():
+    """Two libraries (bf16 / fp16) are loaded side by side, each with its own thread-local message."""
+    from layerskip_amd import _lib
+    a, b = _lib.load(dtype="bf16"), _lib.load(dtype="fp16")
+    out = ctypes.c_size_t(0)
+    assert a.lsk_packed_bytes(16, 100, ctypes.byref(out)) != 0
+    assert b.lsk_packed_bytes(-1, 64, ctypes.byref(out)) != 0
+    import pytest
+    with pytest.raises(_lib.LskError, match="k=100"):
+        _lib.check(1, a)
+    with pytest.raises(_lib.LskError, match="n_rows=-1"):
+        _lib.check(1, b)

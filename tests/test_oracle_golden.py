@@ -52,6 +52,21 @@ def test_restatement_reproduces_reference_bf16(name):
     _check(ar.predicted_tokens, gold["ar_tokens"], gold["ar_margins"] + [0.0], name + " ar")
 
 
+FP16_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp16")
+
+
+@pytest.mark.parametrize("name", sorted(f[:-5] for f in os.listdir(FP16_DIR) if f.endswith(".json")))
+def test_restatement_reproduces_reference_fp16(name):
+    """fp16 (generate.py:63's dtype; the fp16 build of the engine is checked against these fixtures)."""
+    import json
+    rec = json.load(open(os.path.join(FP16_DIR, name + ".json")))
+    spec, ar = _run(rec, torch.float16)
+    gold = rec["fp16"]
+    _check(spec.predicted_tokens, gold["spec_tokens"], gold["spec_margins"] + [0.0], name + " spec")
+    _check(ar.predicted_tokens, gold["ar_tokens"], gold["ar_margins"] + [0.0], name + " ar")
+    assert gold["spec_equals_ar"]          # in fp16 the reference is self-consistent on these cases (SURVEY section 7)
+
+
 def test_reference_helper_semantics():
     """What the reference's own unit tests pin (tests/test_llama_model_utils.py:14-69), on the restatement."""
     m = lo.make_causal_mask(5, torch.float32, 3)
