@@ -157,3 +157,35 @@ def test_eos_list_is_never_silently_truncated():
     assert eng._eos_array([])[0] == []
     with pytest.raises(LskError):
         eng._eos_array(list(range(LSK_MAX_EOS + 1)))
+
+
+def test_engine_status_checks_use_the_engines_own_library():
+    """Every C-ABI call of HipEngine goes through `_ck`, which reads the message of the library that engine loaded
+    (two libraries -- bf16 and fp16 -- can be resident).  Exercised with a stub library: no device needed."""
+    import ctypes
+    from layerskip_amd._lib import LskError
+    from layerskip_amd.engine import HipEngine
+
+    class StubLib:
+        def __init__(self):
+            self.fail = False
+
+        def lsk_engine_get_kv_len(self, handle, out):
+            ctypes.cast(out, ctypes.POINTER(ctypes.c_int32))[0] = 41
+            return 1 if self.fail else 0
+
+        def lsk_engine_set_option(self, handle, option, value):
+            return 1 if self.fail else 0
+
+        def lsk_last_error(self):
+            return b"stub says no"
+
+    eng = object.__new__(HipEngine)
+    eng.lib, eng._handle = StubLib(), ctypes.c_void_p(None)
+    assert eng.kv_len == 41
+    eng.set_option(3, 1)
+    eng.lib.fail = True
+    with pytest.raises(LskError, match="stub says no"):
+        eng.set_option(3, 1)
+    with pytest.raises(LskError, match="stub says no"):
+        _ = eng.kv_len
