@@ -101,3 +101,44 @@ class CpuStageBackend:
 
     def write_rows(self, buffer, row_base, rows):
         self.buf[buffer][row_base:row_base + rows.shape[0]] = rows.float()
+
+    # ---- the orchestration of lsk_spec_step_sampled (layerskip_hip.hip) with the oracle's model of the two kernels
+    def spec_step_sampled(self, input_ids, num_speculations, exit_layer, eos_token_ids, temperature, top_k, top_p, seed, offset):
+        import numpy as np
+        from layerskip_amd.engine import StepResult
+        from oracle import sampling_oracle as so
+        ids, S, E, L = list(input_ids), int(num_speculations), int(exit_layer), self.num_layers
+        P = len(ids)
+        eos = [t for t in eos_token_ids if 0 <= t < self.vocab]
+
+        def logits_rows(buffer, row_base, m):
+            out = torch.zeros(m, self.vocab)
+            self.run_head(buffer, row_base, m, logits=out, want_tokens=False)
+            return out.to(torch.bfloat16).float().numpy()          # the engine's logits are rounded to the model dtype
+
+        if P > 1:
+            self.embed_rows(ids[:-1], 1, 0)
+            self.run_bulk(P - 1, 0, E)
+        row_tokens, p_draft = [ids[-1]], []
+        for j in range(S + 1):
+            self.embed_rows([row_tokens[j]], 0, j)
+            self.run_layers(0, j, 1, P - 1 + j, 0, E)
+            if j < S:
+                tok, probs = so.device_sample_row(logits_rows(0, j, 1)[0], temperature, top_k, top_p, seed, offset, j)
+                row_tokens.append(tok)
+                p_draft.append(probs)
+        if P > 1:
+            self.run_bulk(P - 1, E, L)
+        self.run_layers(0, 0, S + 1, P - 1, E, L)
+        vl = logits_rows(0, 0, S + 1)
+        verified, p_verify = [], []
+        for r in range(S + 1):
+            tok, probs = so.device_sample_row(vl[r], temperature, top_k, top_p, seed, offset, so.TAG_VERIFY + r)
+            verified.append(tok)
+            p_verify.append(probs)
+        drafts = row_tokens[1:]
+        n, td, nxt = so.device_accept(drafts, verified, p_draft if p_draft else [np.zeros(self.vocab, np.float32)], p_verify, eos, seed, offset)
+        if n < td:
+            verified[n] = nxt
+        self._kv_len += P + n
+        return StepResult(n, td, nxt, self._kv_len, drafts[:n] + [nxt], drafts, verified)

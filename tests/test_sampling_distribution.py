@@ -23,7 +23,11 @@ def _tv(a, b):
     return 0.5 * sum(abs(a.get(k, 0) / na - b.get(k, 0) / nb) for k in keys)
 
 
-def test_sampled_speculation_matches_reference_in_distribution(monkeypatch):
+@pytest.mark.parametrize("device_sampling", [False, True], ids=["host-sampling", "device-algorithm"])
+def test_sampled_speculation_matches_reference_in_distribution(monkeypatch, device_sampling):
+    """host-sampling: the strategies' default `sample=True` path (logits materialised, torch draws).
+    device-algorithm: the orchestration of lsk_spec_step_sampled with the oracle's draw-for-draw model of the two
+    sampling kernels (key-space thresholds, Philox + Gumbel-max, rejection step) -- the algorithm the device runs."""
     import copy
     from cpu_stage_backend import CpuStageBackend
     from layerskip_amd import GenerationConfig, hip_strategies
@@ -50,7 +54,9 @@ def test_sampled_speculation_matches_reference_in_distribution(monkeypatch):
 
     backend = CpuStageBackend(base)
     monkeypatch.setattr(hip_strategies, "get_engine", lambda model, **k: backend)
-    mine = hip_strategies.HipSelfSpeculativeGenerationStrategy()
+    mine = hip_strategies.HipSelfSpeculativeGenerationStrategy(device_sampling=device_sampling)
+    if not device_sampling:
+        monkeypatch.delattr(CpuStageBackend, "spec_step_sampled")      # the host path must not depend on it
     my_acc, my_first, my_len = [], collections.Counter(), []
     for i in range(N_RUNS):
         torch.manual_seed(5000 + i)
