@@ -85,6 +85,16 @@ PROTOTYPES = {
     "lsk_write_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "lsk_test_gemm": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_int32, c_void_p]),
     "lsk_test_accept": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "lsk_test_qkv": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_float, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                               c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lsk_test_swiglu": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p]),
+    "lsk_test_resid": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "lsk_test_head_scratch_bytes": (c_int32, [c_int32, POINTER(c_size_t)]),
+    "lsk_test_head": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                c_void_p, c_void_p]),
+    "lsk_test_attention_scratch_bytes": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "lsk_test_attention": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                     c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int32, c_void_p]),
     "lsk_time_gateup": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p]),
     "lsk_engine_set_profile": (c_int32, [c_void_p, c_int32]),
     "lsk_engine_get_profile": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32)]),

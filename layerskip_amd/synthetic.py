@@ -67,6 +67,22 @@ SHAPES: Dict[str, dict] = {
                      num_attention_heads=32, num_key_value_heads=32, head_dim=128,
                      vocab_size=32000, rope_theta=10000.0, max_position_embeddings=4096,
                      exit_layer=2, num_speculations=6),
+    # 4-layer slices with the exact projection / vocabulary / RoPE geometry of the other BASELINE configs
+    "slice-8B": dict(num_hidden_layers=4, hidden_size=4096, intermediate_size=14336,
+                     num_attention_heads=32, num_key_value_heads=8, head_dim=128,
+                     vocab_size=128256, rope_theta=500000.0, max_position_embeddings=8192,
+                     exit_layer=2, num_speculations=6),
+    "slice-13B": dict(num_hidden_layers=4, hidden_size=5120, intermediate_size=13824,
+                      num_attention_heads=40, num_key_value_heads=40, head_dim=128,
+                      vocab_size=32000, rope_theta=10000.0, max_position_embeddings=4096,
+                      exit_layer=2, num_speculations=8),
+    "slice-1B": dict(num_hidden_layers=4, hidden_size=2048, intermediate_size=8192,
+                     num_attention_heads=32, num_key_value_heads=8, head_dim=64,
+                     vocab_size=128256, rope_theta=500000.0, tie_word_embeddings=True,
+                     rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0,
+                                       high_freq_factor=4.0,
+                                       original_max_position_embeddings=8192),
+                     max_position_embeddings=131072, exit_layer=2, num_speculations=4),
     # Wide enough that K > 4096 (two K-chunks in every projection) like 70B / 13B.
     "small-wide": dict(num_hidden_layers=4, hidden_size=5120, intermediate_size=6144,
                        num_attention_heads=40, num_key_value_heads=8, head_dim=128,
@@ -203,3 +219,146 @@ class SyntheticCase:
         if c.num_speculations is None:
             c.num_speculations = default_num_speculations(self.shape)
         return c
+
+
+# --------------------------------------------------------------------------------------------------
+# Structured checkpoints: greedy decoding with HEALTHY top-2 margins on every decision.
+# --------------------------------------------------------------------------------------------------
+# Random-init logits are Gaussian, so a few percent of greedy decisions are ties at bf16 resolution and no
+# fixture built from them can show token-exact parity (the reference is not even reproducible against itself
+# there).  A structured checkpoint makes every decision of the draft head AND of the full model a wide-margin
+# one while every kernel still does real arithmetic:
+#   * token embeddings are random UNIT vectors u_t; lm_head rows are the same directions (tied, or an untied
+#     noisy copy), the final RMSNorm gain scales the logits to <= ~16;
+#   * an "active" vocabulary A is ordered into one cycle pi; a lookup MLP in an EARLY layer (gate/up rows keyed
+#     on u_t, down column 4*u_pi(t)) makes the early-exit head predict pi(t);
+#   * a lookup MLP in a LATE layer, keyed on u_pi(t) for t in a subset B of A, adds 16*u_sigma(t) with
+#     sigma = pi^jump: the full model predicts sigma(t) for t in B and pi(t) otherwise.  Drafts are therefore
+#     rejected exactly behind tokens of B: |B|/|A| sets the acceptance rate (the role damping played for the
+#     random checkpoints);
+#   * all other weights are small random matrices; q/k give O(1) score spreads and v/o carry an identity
+#     component, so the whole context (every KV entry, RoPE, the masks) moves the logits by many bf16 ulp --
+#     visible to the teacher-forced logits tests -- without ever approaching the decision margins.
+STRUCT_DEFAULTS = dict(active=96, override_frac=0.3, jump=3, early_gain=4.0, late_gain=16.0, key_gain=6.0,
+                       logit_scale=16.0, noise=0.5, down_noise=2.0, mix=2.0, qk_gain=1.6, head_noise=0.02)
+
+
+def _unit_rows(n: int, h: int, g: torch.Generator) -> torch.Tensor:
+    v = torch.randn(n, h, generator=g, dtype=torch.float32)
+    return v / v.norm(dim=1, keepdim=True)
+
+
+@torch.no_grad()
+def build_structured_model(config: transformers.LlamaConfig, seed: int = 0, exit_layer: int = 2,
+                           dtype: torch.dtype = torch.bfloat16, device: str | torch.device = "cpu",
+                           layer_range: Optional[tuple] = None, **knobs) -> transformers.LlamaForCausalLM:
+    """Deterministic (CPU generator) structured ``LlamaForCausalLM``; see the block comment above.
+    The token program is attached as ``model.struct_program`` (dict: active, pi, sigma, override).
+
+    Scales (x = RMS-normed residual row, |x| = sqrt(H)): q/k rows ~ N(0, 1/H) (scores of std ~1); v = x on the kv
+    dims / sqrt(H) plus noise, o scatters each head back with weight ``mix`` plus noise: an attention block moves
+    the residual by <~ 0.3 at |h| >= 1; random gate/up pre-activations ~ N(0, noise^2), random down columns
+    sized so that an MLP block moves it by ~0.3 as well; the lookup rows give 4 (early) and 16 (late)."""
+    k = dict(STRUCT_DEFAULTS)
+    k.update(knobs)
+    device = torch.device(device)
+    H, I, L, V = config.hidden_size, config.intermediate_size, config.num_hidden_layers, config.vocab_size
+    hd = getattr(config, "head_dim", None) or H // config.num_attention_heads
+    nh, nkv = config.num_attention_heads, config.num_key_value_heads
+    n_act = int(min(k["active"], I // 2, V - 3))
+    if not (1 <= exit_layer < L):
+        raise ValueError("exit_layer must be in [1, num_layers)")
+    g = torch.Generator().manual_seed((seed * 2654435761 + 97) % (2 ** 63 - 1))
+    with torch.device("meta"):
+        model = transformers.LlamaForCausalLM(config)
+    model.eval()
+    tied = bool(getattr(config, "tie_word_embeddings", False))
+    rs = 1.0 / (H ** 0.5)
+
+    def put(name, value):
+        _assign(model, name, value.to(dtype).to(device))
+
+    embed = _unit_rows(V, H, g)
+    put("model.embed_tokens.weight", embed)
+    if tied:
+        model.lm_head.weight = model.model.embed_tokens.weight
+    else:
+        put("lm_head.weight", embed + k["head_noise"] * rs * torch.randn(V, H, generator=g))
+    put("model.norm.weight", torch.full((H,), k["logit_scale"] * rs) * (1.0 + 0.05 * torch.randn(H, generator=g)))
+    # ---- token program -------------------------------------------------------------------------
+    perm = torch.randperm(V - 3, generator=g)[:n_act] + 3
+    cyc = perm.tolist()
+    pi = {cyc[i]: cyc[(i + 1) % n_act] for i in range(n_act)}
+    jump = max(2, int(k["jump"]))
+    pos_of = {t: i for i, t in enumerate(cyc)}
+    sigma = {t: cyc[(pos_of[t] + jump) % n_act] for t in cyc}
+    n_over = max(1, int(round(k["override_frac"] * n_act)))
+    override = [cyc[i] for i in torch.randperm(n_act, generator=g)[:n_over].tolist()]
+    early_layer, late_layer = 0, exit_layer
+    kg = k["key_gain"] * rs          # gate/up rows: kg * u  ->  pre-activation key_gain * cos(x, u)
+    act = k["key_gain"] * k["key_gain"] * (1.0 / (1.0 + 2.718281828 ** (-k["key_gain"])))   # silu(g) * u at cos = 1
+    kvd = min(nkv * hd, H)
+    group = nh // nkv
+    for idx in range(L):
+        p = f"model.layers.{idx}."
+        # every layer draws the same amount of randomness whether or not this rank materialises it
+        n1 = 1.0 + 0.1 * torch.randn(H, generator=g)
+        n2 = 1.0 + 0.1 * torch.randn(H, generator=g)
+        wq = k["qk_gain"] * rs * torch.randn(nh * hd, H, generator=g)
+        wk = k["qk_gain"] * rs * torch.randn(nkv * hd, H, generator=g)
+        wv = k["noise"] * rs * rs * torch.randn(nkv * hd, H, generator=g)
+        wo = k["noise"] * torch.randn(H, nh * hd, generator=g) / ((nh * hd) ** 0.5)
+        wg = k["noise"] * rs * torch.randn(I, H, generator=g)
+        wu = k["noise"] * rs * torch.randn(I, H, generator=g)
+        wd = k["down_noise"] * torch.randn(H, I, generator=g) / ((I * H) ** 0.5)
+        if layer_range is not None and not (layer_range[0] <= idx < layer_range[1]):
+            continue
+        # identity component: v = x[kv dims] / sqrt(H); o scatters head h's output back onto those dims
+        wv[torch.arange(kvd), torch.arange(kvd)] += rs
+        for h in range(nh):
+            kvh = h // group
+            rows = torch.arange(kvh * hd, min((kvh + 1) * hd, H))
+            if rows.numel():
+                wo[rows, h * hd + (rows - kvh * hd)] += k["mix"] / (group * L ** 0.5)
+        if idx == early_layer:
+            keys = embed[cyc]                                   # [n_act, H] key on u_t
+            vals = embed[[pi[t] for t in cyc]]                  # value u_pi(t)
+            wg[:n_act] = kg * keys
+            wu[:n_act] = kg * keys
+            wd[:, :n_act] = (k["early_gain"] / act) * vals.t()
+        if idx == late_layer:
+            keys = embed[[pi[t] for t in override]]             # key on the early path's prediction u_pi(t)
+            vals = embed[[sigma[t] for t in override]]
+            wg[:n_over] = kg * keys
+            wu[:n_over] = kg * keys
+            wd[:, :n_over] = (k["late_gain"] / act) * vals.t()
+        put(p + "input_layernorm.weight", n1)
+        put(p + "post_attention_layernorm.weight", n2)
+        put(p + "self_attn.q_proj.weight", wq)
+        put(p + "self_attn.k_proj.weight", wk)
+        put(p + "self_attn.v_proj.weight", wv)
+        put(p + "self_attn.o_proj.weight", wo)
+        put(p + "mlp.gate_proj.weight", wg)
+        put(p + "mlp.up_proj.weight", wu)
+        put(p + "mlp.down_proj.weight", wd)
+    rotary = type(model.model.rotary_emb)(config).to(device)
+    model.model.rotary_emb = rotary
+    model.requires_grad_(False)
+    model.struct_program = {"active": cyc, "pi": pi, "sigma": sigma, "override": sorted(override),
+                            "early_layer": early_layer, "late_layer": late_layer}
+    return model
+
+
+def struct_next_token(program: dict, tok: int, full: bool) -> int:
+    """What the structured checkpoint is built to emit after ``tok``: the early-exit head's pi(t), or the full
+    model's sigma(t) behind an override token."""
+    if full and tok in set(program["override"]):
+        return program["sigma"][tok]
+    return program["pi"][tok]
+
+
+def make_struct_prompt(program: dict, length: int, seed: int) -> List[int]:
+    """``length`` tokens drawn from the checkpoint's active vocabulary (CPU generator)."""
+    g = torch.Generator().manual_seed(5000 + seed)
+    act = program["active"]
+    return [act[i] for i in torch.randint(0, len(act), (length,), generator=g).tolist()]

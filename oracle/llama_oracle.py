@@ -332,6 +332,10 @@ class GenerationTrace:
     steps: List[StepTrace] = field(default_factory=list)
     # top-1 minus top-2 of the (model-dtype) verify logits row that produced each emitted token
     margins: List[float] = field(default_factory=list)
+    # the same for every draft-head decision of the run (SSG:140-141), in units of the bf16 ulp of the top logit;
+    # and the emitted-token margins in those units: what "a healthy decision" is measured in (scale invariant)
+    draft_margins_ulp: List[float] = field(default_factory=list)
+    margins_ulp: List[float] = field(default_factory=list)
 
 
 def _margin(logits_row: torch.Tensor) -> float:
@@ -339,8 +343,23 @@ def _margin(logits_row: torch.Tensor) -> float:
     return float(top2[0] - top2[1])
 
 
+def bf16_ulp(value: float) -> float:
+    """Spacing of bf16 numbers at |value| (8 significand bits)."""
+    import math
+    a = abs(float(value))
+    if a == 0.0 or not math.isfinite(a):
+        return 2.0 ** -133
+    return 2.0 ** (math.floor(math.log2(a)) - 7)
+
+
+def _margin_ulp(logits_row: torch.Tensor) -> float:
+    top2 = torch.topk(logits_row.float(), 2).values
+    return float(top2[0] - top2[1]) / bf16_ulp(float(top2[0]))
+
+
 def single_step_speculation(om, input_ids, input_ids_list, output_ids, num_speculations, past, eos_token_ids,
-                            exit_layer, margins: Optional[List[float]] = None):
+                            exit_layer, margins: Optional[List[float]] = None, draft_margins_ulp: Optional[List[float]] = None,
+                            margins_ulp: Optional[List[float]] = None):
     """SSG:102-229, sample=False, no processors / criteria / streamer."""
     prompt_length = input_ids.size(1)
     draft_input = input_ids.clone()
@@ -351,6 +370,8 @@ def single_step_speculation(om, input_ids, input_ids_list, output_ids, num_specu
         past, eqc = r.past, r.exit_query_cache
         tok = int(decode_next_token_greedy(r.logits, token_idx=-1).item())
         drafts.append(tok)
+        if draft_margins_ulp is not None:
+            draft_margins_ulp.append(_margin_ulp(r.logits[0, -1]))
         draft_input = torch.tensor([[tok]])
         if tok in eos_token_ids:
             break
@@ -370,6 +391,9 @@ def single_step_speculation(om, input_ids, input_ids_list, output_ids, num_specu
     if margins is not None:
         for i in range(n + 1):
             margins.append(_margin(vlogits[0, i]))
+    if margins_ulp is not None:
+        for i in range(n + 1):
+            margins_ulp.append(_margin_ulp(vlogits[0, i]))
     past = crop_past(past, len(input_ids_list) + len(output_ids) - 1)  # SSG:219-221
     return new_input, output_ids, past, n, len(drafts), StepTrace(len(drafts), n, list(drafts), verified[0].tolist())
 
@@ -384,10 +408,12 @@ def self_speculative_generate(om: OracleModel, input_ids: List[int], eos_token_i
     gens = 0
     steps: List[StepTrace] = []
     margins: List[float] = []
+    dm_ulp: List[float] = []
+    m_ulp: List[float] = []
     while len(out) < max_steps:
         ids, out, past, n, td, tr = single_step_speculation(
             om, ids, input_ids, out, min(num_speculations, max_steps - len(out) - 1), past, eos_token_ids,
-            exit_layer, margins)
+            exit_layer, margins, dm_ulp, m_ulp)
         steps.append(tr)
         matches += n
         gens += td
@@ -400,7 +426,7 @@ def self_speculative_generate(om: OracleModel, input_ids: List[int], eos_token_i
         if eos_found:
             break
     rate = matches / gens  # ZeroDivisionError when no draft was ever made, like SSG:98
-    return GenerationTrace(out, rate, steps, margins[: len(out)])
+    return GenerationTrace(out, rate, steps, margins[: len(out)], dm_ulp, m_ulp[: len(out)])
 
 
 def autoregressive_generate(om: OracleModel, input_ids: List[int], eos_token_ids: List[int], max_steps: int,

@@ -36,6 +36,40 @@ def build_case_model(rec, device="cpu"):
     return model
 
 
+STRUCT_DIR = os.path.join(GOLDEN_DIR, "struct")
+
+
+def struct_names(include_big=True):
+    """Fixtures recorded from the unmodified reference on the STRUCTURED checkpoints (oracle/make_golden_struct.py):
+    every decision of the reference run has a top-2 margin >= 16 bf16 ulp, so they are compared with NO tie branch."""
+    names = sorted(f[:-5] for f in os.listdir(STRUCT_DIR) if f.endswith(".json"))
+    return [n for n in names if include_big or not n.startswith("full")]
+
+
+def load_struct(name):
+    with open(os.path.join(STRUCT_DIR, name + ".json")) as f:
+        return json.load(f)
+
+
+def build_struct_model(rec, device="cpu"):
+    """The deterministic structured checkpoint of a record (CPU generator: the same bits on every box)."""
+    import torch
+    from layerskip_amd import synthetic
+    cfg = synthetic.make_config(rec["shape"])
+    model = synthetic.build_structured_model(cfg, seed=rec["seed"], exit_layer=rec["exit_layer"], dtype=torch.bfloat16,
+                                             device="cpu", **rec.get("knobs", {}))
+    if device != "cpu":
+        model = model.to(device)
+    return model
+
+
+def bf16_ulp(value):
+    """Spacing of bf16 numbers at |value| (python float)."""
+    import math
+    a = abs(float(value))
+    return 2.0 ** -133 if a == 0.0 else 2.0 ** (math.floor(math.log2(a)) - 7)
+
+
 @pytest.fixture(scope="session")
 def gpu_device():
     import torch
