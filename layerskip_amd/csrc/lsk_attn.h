@@ -103,6 +103,19 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
+    // Slots beyond the last key any row can see were never written: the pool is caller-owned memory and may hold
+    // anything there, NaN / Inf bit patterns included.  K is harmless (masked scores are SELECTED away, never
+    // multiplied), V is not (P = 0 times NaN): zero those V elements.  Only the last page in reach has any.
+    {
+        const int nvalid = base_pos + M - (key0 + w * 32 + g * 8);       // valid keys of this lane's run of 8
+        if (nvalid < 8) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j >= nvalid) vb[dt][j] = (elem_t)0.0f;
+        }
+    }
 
     // ---- S = Q K^T (C layout: column = key, rows g*4 + r) ----
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -347,6 +360,16 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(cons
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
+            {   // never-written slots behind this block's last key may hold NaN: zero their V (see lsk_attn_body)
+                const int nvalid = last_key + 1 - (key0 + g * 8);
+                if (nvalid < 8) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (j >= nvalid) vb[dt][j] = (elem_t)0.0f;
+                }
+            }
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {

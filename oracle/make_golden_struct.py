@@ -104,8 +104,10 @@ def pick_rows(p_len: int, n: int, count: int = 12):
     return sorted(r for r in rows if 0 <= r < n)
 
 
-def logits_rows(logits: torch.Tensor, rows, k=16, stride_n=16):
-    """Per row: the top-k entries plus `stride_n` entries at a fixed stride (bf16 values, exactly representable as floats)."""
+def logits_rows(logits: torch.Tensor, rows, k=16, stride_n=16, exact: Optional[torch.Tensor] = None):
+    """Per row: the top-k entries plus `stride_n` entries at a fixed stride (bf16 values, exactly representable as floats).
+    `exact`: the reference's fp32 logits of the same sequence; recorded beside them as `val_fp32` (what both bf16 runs --
+    the reference's and the engine's -- approximate)."""
     out = []
     v = logits.shape[-1]
     for r in rows:
@@ -114,11 +116,15 @@ def logits_rows(logits: torch.Tensor, rows, k=16, stride_n=16):
         step = max(1, v // stride_n)
         idx += [i for i in range(r % step, v, step)][:stride_n]
         idx = sorted(set(idx))
-        out.append({"row": int(r), "idx": idx, "val": [float(row[i]) for i in idx]})
+        rec = {"row": int(r), "idx": idx, "val": [float(row[i]) for i in idx]}
+        if exact is not None:
+            rec["val_fp32"] = [float(exact[r, i]) for i in idx]
+        out.append(rec)
     return out
 
 
-def one_dtype(ref, model_bf16, case, prompt, eos, dtype, inplace: bool):
+def one_dtype(ref, model_bf16, case, prompt, eos, dtype, inplace: bool, exact=None):
+    """exact: (seq, full-depth fp32 logits, early-exit fp32 logits) of the reference's fp32 run, or None."""
     model = model_bf16 if (inplace and dtype == torch.bfloat16) else copy.deepcopy(model_bf16).to(dtype)
     ref_shim.patch_model(model)
     t0 = time.time()
@@ -150,13 +156,14 @@ def one_dtype(ref, model_bf16, case, prompt, eos, dtype, inplace: bool):
         "spec_equals_ar": ref_spec.predicted_tokens == ref_ar.predicted_tokens,
         "min_margin_ulp": min(mine_spec.margins_ulp) if mine_spec.margins_ulp else None,
         "min_draft_margin_ulp": min(mine_spec.draft_margins_ulp) if mine_spec.draft_margins_ulp else None,
-        "logits": logits_rows(my_logits, rows),
-        "early_logits": logits_rows(my_early, rows[::3]),
+        "logits": logits_rows(my_logits, rows, exact=exact[1] if exact and exact[0] == seq else None),
+        "early_logits": logits_rows(my_early, rows[::3], exact=exact[2] if exact and exact[0] == seq else None),
         "reference_spec_seconds": round(t_spec, 2),
     }
+    keep = (seq, my_logits.float().clone(), my_early.float().clone()) if dtype == torch.float32 else None
     del om, model
     gc.collect()
-    return rec
+    return rec, keep
 
 
 def build_case(ref, name, case, eos=None):
@@ -179,9 +186,11 @@ def build_case(ref, name, case, eos=None):
         "override_tokens": prog["override"],
     }
     big = sum(p.numel() for p in model.parameters()) > 2e9
-    dtypes = [("bf16", torch.bfloat16)] + ([("fp32", torch.float32)] if case.fp32 else [])
+    dtypes = ([("fp32", torch.float32)] if case.fp32 else []) + [("bf16", torch.bfloat16)]
+    exact = None
     for dname, dtype in dtypes:
-        rec[dname] = one_dtype(ref, model, case, prompt, eos, dtype, inplace=big)
+        rec[dname], keep = one_dtype(ref, model, case, prompt, eos, dtype, inplace=big, exact=exact)
+        exact = keep or exact
         r = rec[dname]
         print(f"  {name} {dname}: {len(r['spec_tokens'])} tokens, acceptance {r['acceptance_rate']:.3f}, spec==ar "
               f"{r['spec_equals_ar']}, min margin {r['min_margin_ulp']:.1f} ulp (draft {r['min_draft_margin_ulp']:.1f}), "

@@ -148,7 +148,7 @@ def test_qkv_rope_kv_append_bit_exact(gpu_device, shape_name, n_heads, n_kv, hd,
         assert torch.equal(kp[page, :, slot, :], kr[i]), f"K row of position {p}"
         assert torch.equal(vp[page, :, :, slot], v[i]), f"V^T column of position {p}"
     # nothing else in the pool was written
-    assert bool((kp[~touched] == 7.0).all()) and bool((vp.permute(0, 3, 1, 2)[~touched] == 7.0).all())
+    assert bool((kp.permute(0, 2, 1, 3)[~touched] == 7.0).all()) and bool((vp.permute(0, 3, 1, 2)[~touched] == 7.0).all())
 
 
 @pytest.mark.parametrize("m,H,I", [(1, 512, 1408), (7, 4096, 1024), (16, 5120, 256)])
@@ -209,21 +209,30 @@ def test_lm_head_exact_ties_resolve_to_lowest_index(gpu_device, m, V, target_wgs
     # row r of the activations gets its own winner direction, copied into several vocabulary rows
     tiles = (V + 15) // 16
     wg_tiles = max(1, min(8, -(-tiles // (target_wgs or 256))))
-    placements = [
+    base = [
         [5, 9],                                              # same tile
         [16 * 3 + 2, 16 * 4 + 2],                            # neighbouring tiles (same workgroup when it owns > 1 tile)
         [16 * wg_tiles * 2 + 1, 16 * wg_tiles * 7 + 1],      # different workgroups
         [7, V - 1],                                          # first tile and the ragged last tile
-        [V - 3, V - 2, V - 1],                               # three copies at the end
+        [V - 4, V - 3, V - 2],                               # three copies at the end
         [16 * wg_tiles - 1, 16 * wg_tiles, 16 * wg_tiles * 3 + 15],   # across a workgroup boundary
-        [0, V // 2, V - 1],
+        [0, V // 2, V - 6],
     ]
+    used = set()
+    placements = []
+    for r in range(m):
+        ids = sorted(set((i + 3 * (r // len(base))) for i in base[r % len(base)] if 0 <= i + 3 * (r // len(base)) < V) - used)
+        if not ids:
+            ids = [next(i for i in range(V) if i not in used)]
+        used |= set(ids)
+        placements.append(ids)
     want = []
     for r in range(m):
-        ids = sorted(set(i for i in placements[r % len(placements)] if 0 <= i < V))
+        ids = placements[r]
         for i in ids:
             w[i] = (xn[r].float() * 0.25).to(BF)
         want.append(ids[0])
+    assert sum(len(p) > 1 for p in placements) >= min(m, 3)
     # the torch statement: bf16 logits, first max wins
     logits_ref = (xn.float() @ w.float().t()).to(BF)
     wp = _packed(V, H, dev)
@@ -240,7 +249,7 @@ def test_lm_head_exact_ties_resolve_to_lowest_index(gpu_device, m, V, target_wgs
     torch.cuda.synchronize()
     got_logits = logits[:, :V].cpu()
     for r in range(m):
-        ids = sorted(set(i for i in placements[r % len(placements)] if 0 <= i < V))
+        ids = placements[r]
         vals = got_logits[r, ids]
         assert bool((vals == vals[0]).all()), "duplicated rows must give bit-identical logits"
         assert float(vals[0]) == float(got_logits[r].max()), "the duplicated row was built to be the maximum"
@@ -308,11 +317,24 @@ def test_attention_matches_fp32_softmax(gpu_device, mode, n_heads, n_kv, hd, m, 
     torch.cuda.synchronize()
     got = out.cpu().double()
     assert bool(torch.isfinite(got).all()), "NaN in unwritten KV slots leaked into the output"
-    err = (got - ref).abs()
-    # P is rounded to bf16 before P V (as HF's eager path and torch's flash kernels do): one bf16 ulp of the result,
-    # measured at the row's own scale for elements that cancel to ~0
-    scale = ref.abs().clamp_min(ref.abs().amax(dim=-1, keepdim=True) / 16)
-    ulp = _bf16_ulp(scale)
-    frac = float((err <= ulp).double().mean())
+    # P is rounded to bf16 before P V (as HF's eager path and torch's flash kernels do), so the result carries that noise
+    # on top of its own rounding.  Unit: one bf16 ulp of the element, never finer than the ulp of the head vector's RMS
+    # (an element that cancels to ~0 inherits the noise of the terms it is made of; o_proj consumes the whole vector).
+    ref_h = ref.view(m, n_heads, hd)
+    rms = ref_h.pow(2).mean(-1, keepdim=True).sqrt().expand_as(ref_h).reshape(m, -1)
+    ulp = _bf16_ulp(torch.maximum(ref.abs(), rms))
+    err = (got - ref).abs() / ulp
+    frac = float((err <= 1).double().mean())
     assert frac >= 0.99, f"only {frac:.4f} of the outputs within 1 bf16 ulp"
-    assert bool((err <= 2 * ulp).all()), f"max error {float((err / ulp).max()):.2f} ulp"
+    assert float(err.max()) <= 2.0, f"max error {float(err.max()):.2f} ulp"
+    # and no less accurate than torch's own bf16 SDPA on the same tensors (the kernel the reference runs on a CPU)
+    mask = torch.zeros(m, ctx).masked_fill(keys[0] > rows[0], float("-inf")).to(BF)[None, None]
+    sd = torch.nn.functional.scaled_dot_product_attention(
+        q.transpose(0, 1)[None], k.repeat_interleave(group, dim=1).transpose(0, 1)[None],
+        v.repeat_interleave(group, dim=1).transpose(0, 1)[None], attn_mask=mask, scale=1.0 / math.sqrt(hd))
+    sd = sd[0].transpose(0, 1).reshape(m, -1).double()
+    ulp_e = _bf16_ulp(torch.maximum(ref.abs(), rms / 8))
+    e_mine, e_sdpa = (got - ref).abs() / ulp_e, (sd - ref).abs() / ulp_e
+    assert float((e_mine <= 1).double().mean()) >= float((e_sdpa <= 1).double().mean()) - 0.02, \
+        (float((e_mine <= 1).double().mean()), float((e_sdpa <= 1).double().mean()))
+    assert float(e_mine.pow(2).mean().sqrt()) <= 1.25 * float(e_sdpa.pow(2).mean().sqrt()) + 0.05
