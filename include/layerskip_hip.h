@@ -187,11 +187,15 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
                                      boundaries: DESIGN.md 3.3) */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
 /* ---- sampling on the device (sample=True; GenerationConfig temperature / top_k / top_p, generator_base.py:35-44) ----
- * Round 1: both kernels are checked draw for draw against the oracle on the GPU (tests/test_gpu_zz_sampling.py);
- * lsk_spec_step_sampled's end-to-end check is still opt-in (LSK_EXPERIMENTAL=1) and the strategies' default sampling
- * path still materialises the logits for the host (hip_strategies.py).
+ * Both kernels are checked draw for draw against the oracle's model of them, and lsk_spec_step_sampled end to end against the
+ * host-sampling path and the unmodified reference in distribution, on the GPU (tests/test_gpu_zz_sampling.py).  Parity with
+ * the reference is IN DISTRIBUTION (it draws from torch's generator, in a different order).  Differences in the warping:
+ * probabilities are fp32 (the reference warps in the model dtype); a group of exactly tied logits that straddles the
+ * top-p boundary is kept whole (HF splits it by sort order); top_p outside [0, 1] disables the nucleus filter as in the
+ * reference (llama_model_utils.py:102).
  * Random numbers: Philox4x32-10, key = seed, counter = (element / 4, tag, offset); `offset` must differ between calls
- * that are to be independent (the strategies pass a step counter). */
+ * that are to be independent (the strategies draw a base offset from torch's generator per generation and add the step
+ * index, so torch.manual_seed(s) reproduces a generation). */
 /* bytes of device scratch lsk_spec_step_sampled needs (logits + draft / verify probability rows, fp32) */
 int lsk_sampling_scratch_bytes(const lsk_config* cfg, size_t* out_bytes);
 /* decode_next_token(sample=True) (llama_model_utils.py:123-131) over m rows of device logits ([m][ld] fp32):
@@ -206,6 +210,14 @@ int lsk_spec_step_sampled(lsk_engine* e, const int32_t* input_ids, int32_t promp
                           int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, float temperature,
                           int32_t top_k, float top_p, uint64_t seed, uint64_t offset, void* scratch,
                           size_t scratch_bytes, lsk_step_result* out, void* stream);
+/* SelfSpeculativeGenerationStrategy.generate_token_ids with sample=True and no logits processors / stopping criteria /
+ * streamer as ONE call: lsk_spec_generate's pipelined loop over sampled steps (step i draws from Philox offset + i). */
+int lsk_spec_generate_sampled(lsk_engine* e, const int32_t* prompt_ids, int32_t prompt_len, int32_t num_speculations,
+                              int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, int32_t max_steps,
+                              float temperature, int32_t top_k, float top_p, uint64_t seed, uint64_t offset, void* scratch,
+                              size_t scratch_bytes, int32_t* out_tokens, int32_t* n_out, int32_t* total_matches,
+                              int32_t* total_drafts, int32_t* step_drafts, int32_t* step_matches, int32_t* n_steps,
+                              void* stream);
 /* the rejection-sampling kernel alone (tests): all pointers DEVICE; draft[-1] must be addressable; result int32[64] */
 int lsk_test_accept_sampled(int32_t* draft, int32_t* verified, int32_t num_drafts, const int32_t* eos, int32_t n_eos,
                             const void* p_draft, const void* p_verify, int32_t ld, int32_t vocab, uint64_t seed,
@@ -273,6 +285,12 @@ int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t iters, floa
  * launch stream; lsk_engine_get_profile returns the summed duration and the launch count and clears the log. */
 int lsk_engine_set_profile(lsk_engine* e, int32_t enable);
 int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches);
+/* The same for EVERY kernel class of the decode path: q/k/v (0), attention (1), o_proj (2), gate/up (3), down (4),
+ * lm_head (5), each split into 1-row (draft) and multi-row (verify) passes: arrays of 12 entries, index =
+ * 2 * class + (rows > 1): summed duration (ms), launches, summed ALGORITHMIC bytes (packed weights once; K and V of the
+ * keys in reach once for attention).  Clears the log. */
+#define LSK_PROF_ENTRIES 12
+int lsk_engine_get_profile_table(lsk_engine* e, int32_t n_entries, float* ms, int32_t* launches, double* bytes);
 
 #ifdef __cplusplus
 }

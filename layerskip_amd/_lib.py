@@ -79,6 +79,10 @@ PROTOTYPES = {
                                   c_void_p, c_void_p, c_void_p]),
     "lsk_spec_step_sampled": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, POINTER(c_int32), c_int32, c_float,
                                         c_int32, c_float, c_uint64, c_uint64, c_void_p, c_size_t, POINTER(LskStepResult), c_void_p]),
+    "lsk_spec_generate_sampled": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32,
+                                            c_float, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_size_t, POINTER(c_int32),
+                                            POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                            POINTER(c_int32), c_void_p]),
     "lsk_test_accept_sampled": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                                           c_uint64, c_uint64, c_void_p, c_void_p]),
     "lsk_read_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
@@ -98,6 +102,7 @@ PROTOTYPES = {
     "lsk_time_gateup": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p]),
     "lsk_engine_set_profile": (c_int32, [c_void_p, c_int32]),
     "lsk_engine_get_profile": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32)]),
+    "lsk_engine_get_profile_table": (c_int32, [c_void_p, c_int32, POINTER(c_float), POINTER(c_int32), POINTER(ctypes.c_double)]),
 }
 
 _LIBS: dict = {}

@@ -237,7 +237,12 @@ struct lsk_engine {
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    struct ProfRec { unsigned char cat; unsigned char multi; double bytes; };
+    std::vector<ProfRec> prof_log;   // one record per event pair, in pool order
 };
+
+// kernel classes of the decode path (lsk_engine_get_profile_table); each is split into 1-row and multi-row passes
+enum { LSK_PROF_QKV = 0, LSK_PROF_ATTN = 1, LSK_PROF_OPROJ = 2, LSK_PROF_GATEUP = 3, LSK_PROF_DOWN = 4, LSK_PROF_HEAD = 5, LSK_PROF_CLASSES = 6 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -532,6 +537,21 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
     return 0;
 }
 
+// next (start, stop) event pair of the profile pool (nothing when profiling is off); `bytes` = the launch's algorithmic bytes
+static int profile_pair(lsk_engine* e, int cat, int m, double bytes, hipEvent_t* a, hipEvent_t* b) {
+    *a = nullptr; *b = nullptr;
+    if (!e->profile) return 0;
+    e->prof_log.push_back({(unsigned char)cat, (unsigned char)(m > 1 ? 1 : 0), bytes});
+    while (e->ev_used + 2 > e->ev_pool.size()) {
+        hipEvent_t ev;
+        HIP_OK(hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
+    *a = e->ev_pool[e->ev_used++];
+    *b = e->ev_pool[e->ev_used++];
+    return 0;
+}
+
 static elem_t* buf_rows(lsk_engine* e, int buffer, int row_base) {
     return (buffer == 0 ? e->hrow : e->hbulk) + (size_t)row_base * e->cfg.hidden;
 }
@@ -570,7 +590,13 @@ static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     int pages = 0;
     LSK_TRY(attn_params(e, q, out, kpool, vpool, m, pos_off, sp, pages));
     const dim3 grid(c.n_heads, pages), block(LSK_ATTN_THREADS);
-    if (hd == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, sp);
+    hipEvent_t ea = nullptr, eb = nullptr;
+    // algorithmic bytes: K and V of every key in reach, once (GQA: each KV head once)
+    LSK_TRY(profile_pair(e, LSK_PROF_ATTN, m, 2.0 * 2.0 * c.n_kv_heads * hd * (double)(e->kv_len_host + pos_off + m), &ea, &eb));
+    if (ea != nullptr) {
+        if (hd == 128) hipExtLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, ea, eb, 0, sp);
+        else hipExtLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, ea, eb, 0, sp);
+    } else if (hd == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, sp);
     else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, sp);
     HIP_OK(hipGetLastError());
     if (e->fused_attn) return 0;
@@ -707,18 +733,6 @@ static int launch_chain(lsk_engine* e, int l, bool with_next_qkv, elem_t* x, int
     return 0;
 }
 
-// next (start, stop) event pair of the profile pool
-static int profile_pair(lsk_engine* e, hipEvent_t* a, hipEvent_t* b) {
-    while (e->ev_used + 2 > e->ev_pool.size()) {
-        hipEvent_t ev;
-        HIP_OK(hipEventCreate(&ev));
-        e->ev_pool.push_back(ev);
-    }
-    *a = e->ev_pool[e->ev_used++];
-    *b = e->ev_pool[e->ev_used++];
-    return 0;
-}
-
 // decoder layers [lb, le) in place over rows of `x` (positions *base_ptr + pos_off + i)
 static int run_layers(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st) {
     const lsk_config& c = e->cfg;
@@ -738,7 +752,9 @@ static int run_layers(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int 
             p.q_out = e->qbuf; p.ldq = qdim; p.kpool = kpool; p.vpool = vpool; p.block_table = e->block_table;
             p.page_size = c.page_size; p.n_heads = c.n_heads; p.n_kv = c.n_kv_heads; p.head_dim = c.head_dim;
             p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin; p.kv_len = base_ptr; p.pos_off = pos_off;
-            LSK_TRY((launch_gemm<PRO_RMS, EPI_QKV>(p, e->target_wgs, st)));
+            hipEvent_t ea = nullptr, eb = nullptr;
+            LSK_TRY(profile_pair(e, LSK_PROF_QKV, m, (double)p.wp_bytes, &ea, &eb));
+            LSK_TRY((launch_gemm<PRO_RMS, EPI_QKV>(p, e->target_wgs, st, nullptr, ea, eb)));
         }
         if (e->fused_oproj && e->fused_attn && m <= 8 && e->heads_epoch < (1 << 24)) {
             LSK_TRY(launch_attn_oproj(e, kpool, vpool, lw, x, m, pos_off, st));
@@ -756,7 +772,9 @@ static int run_layers(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int 
             p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
             p.wp = lw.wo; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
             p.h = x; p.ldh = c.hidden;
-            LSK_TRY((launch_gemm<PRO_PLAIN, EPI_RESID>(p, e->target_wgs, st)));
+            hipEvent_t ea = nullptr, eb = nullptr;
+            LSK_TRY(profile_pair(e, LSK_PROF_OPROJ, m, (double)p.wp_bytes, &ea, &eb));
+            LSK_TRY((launch_gemm<PRO_PLAIN, EPI_RESID>(p, e->target_wgs, st, nullptr, ea, eb)));
         }
         {   // post-attention RMSNorm -> gate/up -> SiLU * up
             GemmParams p{};
@@ -764,7 +782,7 @@ static int run_layers(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int 
             p.wp = lw.wgu; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
             p.norm_w = lw.norm2; p.eps = c.rms_eps; p.act = e->act; p.ldact = c.intermediate;
             hipEvent_t ea = nullptr, eb = nullptr;
-            if (e->profile) LSK_TRY(profile_pair(e, &ea, &eb));
+            LSK_TRY(profile_pair(e, LSK_PROF_GATEUP, m, (double)p.wp_bytes, &ea, &eb));
             LSK_TRY((launch_gemm<PRO_RMS, EPI_SWIGLU>(p, e->target_wgs, st, nullptr, ea, eb)));
         }
         {   // down_proj + residual
@@ -772,7 +790,9 @@ static int run_layers(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int 
             p.x = e->act; p.ldx = c.intermediate; p.M = m; p.K = c.intermediate; p.N = c.hidden; p.n_tiles = p.N / 16;
             p.wp = lw.wdown; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
             p.h = x; p.ldh = c.hidden;
-            LSK_TRY((launch_gemm<PRO_PLAIN, EPI_RESID>(p, e->target_wgs, st)));
+            hipEvent_t ea = nullptr, eb = nullptr;
+            LSK_TRY(profile_pair(e, LSK_PROF_DOWN, m, (double)p.wp_bytes, &ea, &eb));
+            LSK_TRY((launch_gemm<PRO_PLAIN, EPI_RESID>(p, e->target_wgs, st, nullptr, ea, eb)));
         }
     }
     return 0;
@@ -788,7 +808,9 @@ static int run_head(lsk_engine* e, const elem_t* x, int m, float* logits, int ld
     p.norm_w = e->final_norm; p.eps = c.rms_eps;
     p.logits = logits; p.ld_logits = ld_logits; p.part_val = e->part_val; p.part_idx = e->part_idx;
     int grid = 0;
-    LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, e->target_wgs, st, &grid)));
+    hipEvent_t ea = nullptr, eb = nullptr;
+    LSK_TRY(profile_pair(e, LSK_PROF_HEAD, m, (double)p.wp_bytes, &ea, &eb));
+    LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, e->target_wgs, st, &grid, ea, eb)));
     if (grid > e->max_parts) return lsk_fail("internal: head grid %d > max_parts %d", grid, e->max_parts);
     hipLaunchKernelGGL(lsk_argmax_finalize_kernel, dim3(m), dim3(embed_dst ? 256 : 64), 0, st, e->part_val, e->part_idx, grid, m, tokens_dev,
                        e->embed, e->cfg.hidden, e->cfg.vocab, embed_dst);
@@ -913,11 +935,46 @@ static int upload_step_inputs(lsk_engine* e, const int32_t* input_ids, int P, co
     return 0;
 }
 
+// ---- sampling on the device (SURVEY 8f N2; lsk_sample.h) --------------------------------------------------
+static int sampling_ld(const lsk_config& c) { return (c.vocab + 3) / 4 * 4; }
+
+// RNG tags inside one step (Philox counter word 1): draft row j -> j, verify row r -> 32 + r, acceptance uniforms -> 64,
+// residual draw -> 96.  `offset` (counter words 2-3) must differ between steps: the caller passes a step counter.
+#define LSK_TAG_VERIFY 32
+#define LSK_TAG_ACCEPT 64
+#define LSK_TAG_RESIDUAL 96
+
+// sample=True parameters of one step; nullptr = greedy
+struct StepSampling {
+    float temperature;
+    int top_k;
+    float top_p;
+    uint64_t seed, offset;
+    float *logits, *p_draft, *p_verify;     // device scratch: [17][ld], [16][ld], [17][ld]
+    int ld;
+};
+
+static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, float temperature, int top_k, float top_p, uint64_t seed,
+                         uint64_t offset, int tag0, int* tokens_dev, float* probs, elem_t* embed_dst, hipStream_t st) {
+    SampleParams sp{};
+    sp.logits = logits; sp.ld = ld; sp.vocab = e->cfg.vocab; sp.inv_temperature = 1.0f / temperature;
+    sp.top_k = top_k; sp.top_p = top_p;
+    sp.seed_lo = (unsigned int)seed; sp.seed_hi = (unsigned int)(seed >> 32);
+    sp.off_lo = (unsigned int)offset; sp.off_hi = (unsigned int)(offset >> 32);
+    sp.tag0 = tag0; sp.tokens_out = tokens_dev; sp.probs_out = probs;
+    sp.embed = e->embed; sp.hidden = e->cfg.hidden; sp.embed_dst = embed_dst;
+    hipLaunchKernelGGL(lsk_sample_kernel, dim3(m), dim3(LSK_SAMPLE_THREADS), 0, st, sp);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 // Enqueue every kernel of ONE speculation step plus the copy of its result block into pinned slot `slot`.
 // Nothing here needs the outcome of the previous step on the host: positions come from the device-side
 // kv_len, the input token of a continuing step sits in row_tokens[0] (left there by the previous accept
 // kernel).  e->kv_len_host only has to be an UPPER bound (bounds checks, attention pages to launch).
-static int enqueue_step(lsk_engine* e, int P, int S, int E, int n_eos, int slot, hipStream_t st) {
+// sm != nullptr: sample=True -- every argmax becomes a draw from the warped distribution (decode_next_token,
+// llama_model_utils.py:123-131) and the prefix match becomes modified rejection sampling (SSG:191-199), on the device.
+static int enqueue_step(lsk_engine* e, int P, int S, int E, int n_eos, int slot, hipStream_t st, const StepSampling* sm = nullptr) {
     const lsk_config& c = e->cfg;
     const int L = c.num_layers;
     if (e->kv_len_host + P + S > c.max_ctx) return lsk_fail("context overflow: %d + %d + %d > max_ctx %d", e->kv_len_host, P, S, c.max_ctx);
@@ -932,16 +989,38 @@ static int enqueue_step(lsk_engine* e, int P, int S, int E, int n_eos, int slot,
         elem_t* xr = e->hrow + (size_t)j * c.hidden;
         if (j == 0) LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, xr, st));   // rows j > 0 were embedded by the previous head
         LSK_TRY(run_layers(e, xr, 1, kvp, P - 1 + j, 0, E, st));   // j == S: forward_remainder's early pass (LMU:350-362)
-        if (j < S) LSK_TRY(run_head(e, xr, 1, nullptr, 0, e->row_tokens + j + 1, st, xr + c.hidden));
+        if (j < S) {
+            if (sm == nullptr) {
+                LSK_TRY(run_head(e, xr, 1, nullptr, 0, e->row_tokens + j + 1, st, xr + c.hidden));
+            } else {
+                LSK_TRY(run_head(e, xr, 1, sm->logits, sm->ld, e->verified, st));      // the argmax lands in `verified` and is ignored
+                LSK_TRY(launch_sample(e, sm->logits, sm->ld, 1, sm->temperature, sm->top_k, sm->top_p, sm->seed, sm->offset, j,
+                                      e->row_tokens + j + 1, sm->p_draft + (size_t)j * sm->ld, xr + c.hidden, st));
+            }
+        }
     }
     // ---- forward_remainder, late layers (LMU:364-383): exit_query_cache rows + last draft row ----
     if (P > 1) LSK_TRY(run_bulk(e, P - 1, kvp, E, L, st));
     LSK_TRY(run_layers(e, e->hrow, S + 1, kvp, P - 1, E, L, st));
-    LSK_TRY(run_head(e, e->hrow, S + 1, nullptr, 0, e->verified, st));
-    // ---- accept + rollback (SSG:186-221) ----
     int* dres = e->result + slot * 64;
-    hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, st, e->row_tokens + 1, e->verified, S, e->eos, n_eos, P, e->state, dres);
-    HIP_OK(hipGetLastError());
+    if (sm == nullptr) {
+        LSK_TRY(run_head(e, e->hrow, S + 1, nullptr, 0, e->verified, st));
+        // ---- accept + rollback (SSG:186-221) ----
+        hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, st, e->row_tokens + 1, e->verified, S, e->eos, n_eos, P, e->state, dres);
+        HIP_OK(hipGetLastError());
+    } else {
+        LSK_TRY(run_head(e, e->hrow, S + 1, sm->logits, sm->ld, e->verified, st));
+        LSK_TRY(launch_sample(e, sm->logits, sm->ld, S + 1, sm->temperature, sm->top_k, sm->top_p, sm->seed, sm->offset, LSK_TAG_VERIFY,
+                              e->verified, sm->p_verify, nullptr, st));
+        AcceptSampledParams ap{};
+        ap.draft = e->row_tokens + 1; ap.verified = e->verified; ap.num_drafts = S; ap.eos = e->eos; ap.n_eos = n_eos; ap.prompt_len = P;
+        ap.p_draft = sm->p_draft; ap.p_verify = sm->p_verify; ap.ld = sm->ld; ap.vocab = c.vocab;
+        ap.seed_lo = (unsigned int)sm->seed; ap.seed_hi = (unsigned int)(sm->seed >> 32);
+        ap.off_lo = (unsigned int)sm->offset; ap.off_hi = (unsigned int)(sm->offset >> 32);
+        ap.tag_accept = LSK_TAG_ACCEPT; ap.tag_residual = LSK_TAG_RESIDUAL; ap.st = e->state; ap.result = dres;
+        hipLaunchKernelGGL(lsk_accept_sampled_kernel, dim3(1), dim3(LSK_SAMPLE_THREADS), 0, st, ap);
+        HIP_OK(hipGetLastError());
+    }
     HIP_OK(hipMemcpyAsync(e->host_result + slot * 64, dres, sizeof(int) * LSK_RES_INTS, hipMemcpyDeviceToHost, st));
     HIP_OK(hipEventRecord(e->step_done[slot], st));
     return 0;
@@ -989,10 +1068,10 @@ extern "C" int lsk_spec_step(lsk_engine* e, const int32_t* input_ids, int32_t pr
 // SSG:63-66 cannot bind even if every draft is accepted) it is enqueued BEFORE the host waits for that result,
 // so the GPU never idles across a step boundary.  An EOS makes one enqueued step redundant; its effects are
 // confined to KV slots beyond the final length and are discarded.
-extern "C" int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32_t prompt_len, int32_t num_speculations,
-                                 int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, int32_t max_steps,
-                                 int32_t* out_tokens, int32_t* n_out, int32_t* total_matches, int32_t* total_drafts,
-                                 int32_t* step_drafts, int32_t* step_matches, int32_t* n_steps, void* stream) {
+static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t prompt_len, int32_t num_speculations,
+                              int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, int32_t max_steps,
+                              int32_t* out_tokens, int32_t* n_out, int32_t* total_matches, int32_t* total_drafts,
+                              int32_t* step_drafts, int32_t* step_matches, int32_t* n_steps, void* stream, const StepSampling* sm_base) {
     LSK_TRY(ready(e));
     hipStream_t st = (hipStream_t)stream;
     if (!prompt_ids || !out_tokens || !n_out || !total_matches || !total_drafts) return lsk_fail("lsk_spec_generate: null pointer");
@@ -1003,11 +1082,19 @@ extern "C" int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32
     LSK_TRY(lsk_engine_reset(e, stream));
     LSK_TRY(upload_step_inputs(e, prompt_ids, prompt_len, eos_token_ids, n_eos, st));
     int produced = 0, matches = 0, drafts = 0, steps = 0;
+    StepSampling sm_step;
+    uint64_t enq = 0;                        // steps enqueued so far: each one draws from its own Philox offset
+    auto next_sm = [&]() -> const StepSampling* {
+        if (!sm_base) return nullptr;
+        sm_step = *sm_base;
+        sm_step.offset = sm_base->offset + enq++;
+        return &sm_step;
+    };
     int kv_true = 0;                         // verified context length after the last COLLECTED step
     int pend_P = prompt_len, pend_S = S < max_steps - 1 ? S : max_steps - 1, slot = 0;
     if (pend_S < 0) pend_S = 0;
     e->kv_len_host = 0;
-    LSK_TRY(enqueue_step(e, pend_P, pend_S, exit_layer, n_eos, slot, st));
+    LSK_TRY(enqueue_step(e, pend_P, pend_S, exit_layer, n_eos, slot, st, next_sm()));
     bool done = false;
     while (!done) {
         // the pending step emits between 1 and pend_S + 1 tokens; can the next one be decided already?
@@ -1016,7 +1103,7 @@ extern "C" int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32
         int next_slot = slot ^ 1;
         if (early) {
             e->kv_len_host = kv_true + pend_P + pend_S;          // upper bound of the context after the pending step
-            LSK_TRY(enqueue_step(e, 1, S, exit_layer, n_eos, next_slot, st));
+            LSK_TRY(enqueue_step(e, 1, S, exit_layer, n_eos, next_slot, st, next_sm()));
         }
         HIP_OK(hipEventSynchronize(e->step_done[slot]));
         const int* r = e->host_result + slot * 64;
@@ -1041,7 +1128,7 @@ extern "C" int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32
         if (!early) {
             const int s_next = S < max_steps - produced - 1 ? S : max_steps - produced - 1;
             e->kv_len_host = kv_true;
-            LSK_TRY(enqueue_step(e, 1, s_next < 0 ? 0 : s_next, exit_layer, n_eos, next_slot, st));
+            LSK_TRY(enqueue_step(e, 1, s_next < 0 ? 0 : s_next, exit_layer, n_eos, next_slot, st, next_sm()));
             pend_S = s_next < 0 ? 0 : s_next;
         } else {
             pend_S = S;
@@ -1058,6 +1145,14 @@ extern "C" int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32
     *total_drafts = drafts;
     if (n_steps) *n_steps = steps;
     return 0;
+}
+
+extern "C" int lsk_spec_generate(lsk_engine* e, const int32_t* prompt_ids, int32_t prompt_len, int32_t num_speculations,
+                                 int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, int32_t max_steps,
+                                 int32_t* out_tokens, int32_t* n_out, int32_t* total_matches, int32_t* total_drafts,
+                                 int32_t* step_drafts, int32_t* step_matches, int32_t* n_steps, void* stream) {
+    return spec_generate_impl(e, prompt_ids, prompt_len, num_speculations, exit_layer, eos_token_ids, n_eos, max_steps, out_tokens, n_out,
+                              total_matches, total_drafts, step_drafts, step_matches, n_steps, stream, nullptr);
 }
 
 extern "C" int lsk_ar_step(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int32_t layer_end, int32_t* next_token, void* stream) {
@@ -1222,9 +1317,7 @@ extern "C" int lsk_write_rows(lsk_engine* e, int32_t buffer, int32_t row_base, i
     return 0;
 }
 
-// ---- sampling on the device (SURVEY 8f N2; lsk_sample.h) --------------------------------------------------
-static int sampling_ld(const lsk_config& c) { return (c.vocab + 3) / 4 * 4; }
-
+// ---- sampling entry points ---------------------------------------------------------------------------------
 extern "C" int lsk_sampling_scratch_bytes(const lsk_config* cfg, size_t* out_bytes) {
     LSK_TRY(check_cfg(cfg));
     if (!out_bytes) return lsk_fail("null out");
@@ -1233,38 +1326,19 @@ extern "C" int lsk_sampling_scratch_bytes(const lsk_config* cfg, size_t* out_byt
     return 0;
 }
 
-static int check_sampling_args(float temperature, float top_p) {
+// top_p outside [0, 1] means "no nucleus filter", as in the reference (`if 0 <= top_p <= 1.0`, llama_model_utils.py:102)
+static int check_sampling_args(float temperature, float* top_p) {
     if (!(temperature > 0.f)) return lsk_fail("temperature %g must be > 0", (double)temperature);
-    if (!(top_p >= 0.f)) return lsk_fail("top_p %g must be >= 0", (double)top_p);
+    if (!(*top_p >= 0.f) || *top_p > 1.0f) *top_p = 1.0f;
     return 0;
 }
-
-static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, float temperature, int top_k, float top_p, uint64_t seed,
-                         uint64_t offset, int tag0, int* tokens_dev, float* probs, elem_t* embed_dst, hipStream_t st) {
-    SampleParams sp{};
-    sp.logits = logits; sp.ld = ld; sp.vocab = e->cfg.vocab; sp.inv_temperature = 1.0f / temperature;
-    sp.top_k = top_k; sp.top_p = top_p;
-    sp.seed_lo = (unsigned int)seed; sp.seed_hi = (unsigned int)(seed >> 32);
-    sp.off_lo = (unsigned int)offset; sp.off_hi = (unsigned int)(offset >> 32);
-    sp.tag0 = tag0; sp.tokens_out = tokens_dev; sp.probs_out = probs;
-    sp.embed = e->embed; sp.hidden = e->cfg.hidden; sp.embed_dst = embed_dst;
-    hipLaunchKernelGGL(lsk_sample_kernel, dim3(m), dim3(LSK_SAMPLE_THREADS), 0, st, sp);
-    HIP_OK(hipGetLastError());
-    return 0;
-}
-
-// RNG tags inside one step (Philox counter word 1): draft row j -> j, verify row r -> 32 + r, acceptance uniforms -> 64,
-// residual draw -> 96.  `offset` (counter words 2-3) must differ between steps: the caller passes a step counter.
-#define LSK_TAG_VERIFY 32
-#define LSK_TAG_ACCEPT 64
-#define LSK_TAG_RESIDUAL 96
 
 extern "C" int lsk_sample_rows(lsk_engine* e, const void* logits, int32_t ld, int32_t m, float temperature, int32_t top_k, float top_p,
                                uint64_t seed, uint64_t offset, int32_t tag0, int32_t* tokens_out, void* probs_out, void* stream) {
     LSK_TRY(ready(e));
     if (!logits || !tokens_out || !probs_out) return lsk_fail("lsk_sample_rows: null pointer");
     if (m < 1 || m > LSK_MAX_ROWS + 1 || ld < e->cfg.vocab) return lsk_fail("lsk_sample_rows: m=%d ld=%d out of range", m, ld);
-    LSK_TRY(check_sampling_args(temperature, top_p));
+    LSK_TRY(check_sampling_args(temperature, &top_p));
     return launch_sample(e, (const float*)logits, ld, m, temperature, top_k, top_p, seed, offset, tag0, tokens_out, (float*)probs_out, nullptr,
                          (hipStream_t)stream);
 }
@@ -1285,6 +1359,21 @@ extern "C" int lsk_test_accept_sampled(int32_t* draft, int32_t* verified, int32_
     return 0;
 }
 
+static int make_step_sampling(lsk_engine* e, float temperature, int32_t top_k, float top_p, uint64_t seed, uint64_t offset, void* scratch,
+                              size_t scratch_bytes, StepSampling* sm) {
+    LSK_TRY(check_sampling_args(temperature, &top_p));
+    if (!scratch) return lsk_fail("null sampling scratch");
+    size_t need = 0;
+    LSK_TRY(lsk_sampling_scratch_bytes(&e->cfg, &need));
+    if (scratch_bytes < need) return lsk_fail("sampling scratch too small: %zu < %zu", scratch_bytes, need);
+    const int ld = sampling_ld(e->cfg);
+    sm->temperature = temperature; sm->top_k = top_k; sm->top_p = top_p; sm->seed = seed; sm->offset = offset; sm->ld = ld;
+    sm->logits = (float*)scratch;
+    sm->p_draft = sm->logits + (size_t)(LSK_MAX_ROWS + 1) * ld;
+    sm->p_verify = sm->p_draft + (size_t)LSK_MAX_ROWS * ld;
+    return 0;
+}
+
 // single_step_speculation with sample=True (self_speculation_generator.py:101-229, decode_next_token
 // llama_model_utils.py:109-131): the step of lsk_spec_step with every argmax replaced by a draw from the warped
 // distribution and the greedy prefix match replaced by modified rejection sampling -- all on the device.
@@ -1294,50 +1383,13 @@ extern "C" int lsk_spec_step_sampled(lsk_engine* e, const int32_t* input_ids, in
                                      lsk_step_result* out, void* stream) {
     LSK_TRY(ready(e));
     hipStream_t st = (hipStream_t)stream;
-    const lsk_config& c = e->cfg;
-    const int P = prompt_len, S = num_speculations, E = exit_layer, L = c.num_layers;
-    if (!input_ids || !out || !scratch) return lsk_fail("lsk_spec_step_sampled: null pointer");
-    LSK_TRY(validate_step_args(e, P, S, E, eos_token_ids, n_eos));
-    LSK_TRY(check_sampling_args(temperature, top_p));
-    size_t need = 0;
-    LSK_TRY(lsk_sampling_scratch_bytes(&c, &need));
-    if (scratch_bytes < need) return lsk_fail("sampling scratch too small: %zu < %zu", scratch_bytes, need);
-    if (e->kv_len_host + P + S > c.max_ctx) return lsk_fail("context overflow: %d + %d + %d > max_ctx %d", e->kv_len_host, P, S, c.max_ctx);
-    const int ld = sampling_ld(c);
-    float* logits = (float*)scratch;
-    float* p_draft = logits + (size_t)(LSK_MAX_ROWS + 1) * ld;
-    float* p_verify = p_draft + (size_t)LSK_MAX_ROWS * ld;
+    const int P = prompt_len, S = num_speculations;
+    if (!input_ids || !out) return lsk_fail("lsk_spec_step_sampled: null pointer");
+    LSK_TRY(validate_step_args(e, P, S, exit_layer, eos_token_ids, n_eos));
+    StepSampling sm;
+    LSK_TRY(make_step_sampling(e, temperature, top_k, top_p, seed, offset, scratch, scratch_bytes, &sm));
     LSK_TRY(upload_step_inputs(e, input_ids, P, eos_token_ids, n_eos, st));
-    const int* kvp = &e->state->kv_len;
-    if (P > 1) {
-        LSK_TRY(embed_rows_dev(e, e->bulk_ids, P - 1, e->hbulk, st));
-        LSK_TRY(run_bulk(e, P - 1, kvp, 0, E, st));
-    }
-    int* greedy_scratch = e->verified;      // the head kernel's argmax lands here and is ignored
-    for (int j = 0; j <= S; ++j) {
-        elem_t* xr = e->hrow + (size_t)j * c.hidden;
-        if (j == 0) LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, xr, st));
-        LSK_TRY(run_layers(e, xr, 1, kvp, P - 1 + j, 0, E, st));
-        if (j < S) {
-            LSK_TRY(run_head(e, xr, 1, logits, ld, greedy_scratch, st));
-            LSK_TRY(launch_sample(e, logits, ld, 1, temperature, top_k, top_p, seed, offset, j, e->row_tokens + j + 1,
-                                  p_draft + (size_t)j * ld, xr + c.hidden, st));
-        }
-    }
-    if (P > 1) LSK_TRY(run_bulk(e, P - 1, kvp, E, L, st));
-    LSK_TRY(run_layers(e, e->hrow, S + 1, kvp, P - 1, E, L, st));
-    LSK_TRY(run_head(e, e->hrow, S + 1, logits, ld, greedy_scratch, st));
-    LSK_TRY(launch_sample(e, logits, ld, S + 1, temperature, top_k, top_p, seed, offset, LSK_TAG_VERIFY, e->verified, p_verify, nullptr, st));
-    AcceptSampledParams ap{};
-    ap.draft = e->row_tokens + 1; ap.verified = e->verified; ap.num_drafts = S; ap.eos = e->eos; ap.n_eos = n_eos; ap.prompt_len = P;
-    ap.p_draft = p_draft; ap.p_verify = p_verify; ap.ld = ld; ap.vocab = c.vocab;
-    ap.seed_lo = (unsigned int)seed; ap.seed_hi = (unsigned int)(seed >> 32);
-    ap.off_lo = (unsigned int)offset; ap.off_hi = (unsigned int)(offset >> 32);
-    ap.tag_accept = LSK_TAG_ACCEPT; ap.tag_residual = LSK_TAG_RESIDUAL; ap.st = e->state; ap.result = e->result;
-    hipLaunchKernelGGL(lsk_accept_sampled_kernel, dim3(1), dim3(LSK_SAMPLE_THREADS), 0, st, ap);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(e->host_result, e->result, sizeof(int) * LSK_RES_INTS, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipEventRecord(e->step_done[0], st));
+    LSK_TRY(enqueue_step(e, P, S, exit_layer, n_eos, 0, st, &sm));
     HIP_OK(hipEventSynchronize(e->step_done[0]));
     const int* host_res = e->host_result;
     memset(out, 0, sizeof(*out));
@@ -1352,6 +1404,21 @@ extern "C" int lsk_spec_step_sampled(lsk_engine* e, const int32_t* input_ids, in
     e->next_token_host = host_res[2];
     e->kv_len_host = host_res[3];
     return 0;
+}
+
+// generate_token_ids with sample=True as ONE call: lsk_spec_generate's pipelined loop over sampled steps; step i of the
+// call draws from Philox offset `offset + i` (a step made redundant by an EOS consumes one too).
+extern "C" int lsk_spec_generate_sampled(lsk_engine* e, const int32_t* prompt_ids, int32_t prompt_len, int32_t num_speculations,
+                                         int32_t exit_layer, const int32_t* eos_token_ids, int32_t n_eos, int32_t max_steps,
+                                         float temperature, int32_t top_k, float top_p, uint64_t seed, uint64_t offset, void* scratch,
+                                         size_t scratch_bytes, int32_t* out_tokens, int32_t* n_out, int32_t* total_matches,
+                                         int32_t* total_drafts, int32_t* step_drafts, int32_t* step_matches, int32_t* n_steps,
+                                         void* stream) {
+    LSK_TRY(ready(e));
+    StepSampling sm;
+    LSK_TRY(make_step_sampling(e, temperature, top_k, top_p, seed, offset, scratch, scratch_bytes, &sm));
+    return spec_generate_impl(e, prompt_ids, prompt_len, num_speculations, exit_layer, eos_token_ids, n_eos, max_steps, out_tokens, n_out,
+                              total_matches, total_drafts, step_drafts, step_matches, n_steps, stream, &sm);
 }
 
 // ---- single kernels for parity tests / roofline timing -------------------------------------------------
@@ -1550,25 +1617,40 @@ extern "C" int lsk_engine_set_profile(lsk_engine* e, int32_t enable) {
     if (!e) return lsk_fail("null engine");
     e->profile = enable != 0;
     e->ev_used = 0;
+    e->prof_log.clear();
     return 0;
 }
 
-// Sum of the durations of every gate/up launch since lsk_engine_set_profile(e, 1).  Each launch went through
-// hipExtLaunchKernelGGL with its own (start, stop) events, i.e. the dispatch's begin / end timestamps -- the same
-// quantity rocprofv3 --kernel-trace reports -- so no event-record overhead is included.
+// Per kernel class x {1-row, multi-row}: launches, summed duration, summed algorithmic bytes of every decode-path launch
+// since lsk_engine_set_profile(e, 1).  Each launch went through hipExtLaunchKernelGGL with its own (start, stop) events,
+// i.e. the dispatch's begin / end timestamps -- the quantity rocprofv3 --kernel-trace reports -- so no event-record
+// overhead is included.  Arrays of 2 * LSK_PROF_CLASSES entries, index = 2 * class + (rows > 1).  Clears the log.
+extern "C" int lsk_engine_get_profile_table(lsk_engine* e, int32_t n_entries, float* ms, int32_t* launches, double* bytes) {
+    if (!e || !ms || !launches || !bytes) return lsk_fail("null pointer");
+    if (n_entries < 2 * LSK_PROF_CLASSES) return lsk_fail("lsk_engine_get_profile_table: need %d entries", 2 * LSK_PROF_CLASSES);
+    for (int i = 0; i < 2 * LSK_PROF_CLASSES; ++i) { ms[i] = 0.f; launches[i] = 0; bytes[i] = 0.0; }
+    for (size_t r = 0; r < e->prof_log.size() && 2 * r + 1 < e->ev_used; ++r) {
+        float t = 0.f;
+        HIP_OK(hipEventSynchronize(e->ev_pool[2 * r + 1]));
+        HIP_OK(hipEventElapsedTime(&t, e->ev_pool[2 * r], e->ev_pool[2 * r + 1]));
+        const int idx = 2 * e->prof_log[r].cat + e->prof_log[r].multi;
+        ms[idx] += t;
+        launches[idx] += 1;
+        bytes[idx] += e->prof_log[r].bytes;
+    }
+    e->ev_used = 0;
+    e->prof_log.clear();
+    return 0;
+}
+
+// The dominant kernel alone (gate/up projection, both row classes): summed duration and launch count.  Clears the log.
 extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches) {
     if (!e || !total_ms || !launches) return lsk_fail("null pointer");
-    float total = 0.f;
-    int n = 0;
-    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
-        float ms = 0.f;
-        HIP_OK(hipEventSynchronize(e->ev_pool[i + 1]));
-        HIP_OK(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
-        total += ms;
-        ++n;
-    }
-    *total_ms = total;
-    *launches = n;
-    e->ev_used = 0;
+    float ms[2 * LSK_PROF_CLASSES];
+    int32_t n[2 * LSK_PROF_CLASSES];
+    double b[2 * LSK_PROF_CLASSES];
+    LSK_TRY(lsk_engine_get_profile_table(e, 2 * LSK_PROF_CLASSES, ms, n, b));
+    *total_ms = ms[2 * LSK_PROF_GATEUP] + ms[2 * LSK_PROF_GATEUP + 1];
+    *launches = n[2 * LSK_PROF_GATEUP] + n[2 * LSK_PROF_GATEUP + 1];
     return 0;
 }

@@ -56,7 +56,7 @@ class HipEngine:
     def _eos_array(self, eos_token_ids: Sequence[int]):
         """Ids outside the vocabulary can never be produced and are dropped; more than LSK_MAX_EOS real ids is an
         error (never a silent truncation: the device-side draft cut and the host-side output cut must agree)."""
-        eos = [int(t) for t in eos_token_ids if 0 <= int(t) < self.vocab]
+        eos = [int(t) for t in eos_token_ids if t is not None and 0 <= int(t) < self.vocab]     # None: a tokenizer without eos
         if len(eos) > _lib.LSK_MAX_EOS:
             raise _lib.LskError(f"{len(eos)} eos token ids; the engine supports at most {_lib.LSK_MAX_EOS}")
         return eos, _i32_array(eos)
@@ -70,11 +70,7 @@ class HipEngine:
         if weight.dtype == torch.bfloat16:
             self.dtype, dtype_name = torch.bfloat16, "bf16"
         elif weight.dtype == torch.float16:
-            # the fp16 library is the same sources built with -DLSK_ELEM_F16; it has not been run on hardware yet
-            # (written after round 1's GPU budget was spent), so it must be asked for explicitly
-            if os.environ.get("LSK_EXPERIMENTAL") != "1":
-                raise _lib.LskError("the fp16 engine is experimental in this round: set LSK_EXPERIMENTAL=1 to use it, "
-                                    "or load the model in bf16 (torch_dtype=torch.bfloat16)")
+            # the fp16 library: the same sources built with -DLSK_ELEM_F16 (the dtype generate.py:63 hard-codes)
             self.dtype, dtype_name = torch.float16, "fp16"
         else:
             raise _lib.LskError(f"HipEngine computes in bf16 (or fp16); model dtype is {weight.dtype}")
@@ -108,9 +104,14 @@ class HipEngine:
         self._packed = []           # per-layer packed buffers (kept alive); None outside layer_range
         self._globals = {}
         self._buffers = {}
+        self._options = {}          # lsk_engine_set_option values, re-applied whenever the C engine is recreated
+        self._block_table = None
+        self._profile = False
+        self._fingerprint = None
         with torch.cuda.device(self.device):
             self._pack_weights(model)
             self._allocate(max_ctx, max_prompt)
+        self._fingerprint = self._weights_fingerprint(model)
 
     @property
     def model(self):
@@ -119,6 +120,45 @@ class HipEngine:
         return self._model_ref()
 
     # ------------------------------------------------------------------ weights
+    def _weights_fingerprint(self, m):
+        """(storage address, in-place version) of every tensor the engine copied or borrowed.  load_state_dict(), an
+        in-place edit or a LoRA merge bumps the version; assigning a new Parameter changes the address."""
+        if self.release_weights:
+            return None                      # the originals were dropped: the model object only serves this engine
+        fp = []
+        for idx, layer in enumerate(m.model.layers):
+            if not (self.layer_range[0] <= idx < self.layer_range[1]):
+                continue
+            a, mlp = layer.self_attn, layer.mlp
+            for t in (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight,
+                      mlp.down_proj.weight, layer.input_layernorm.weight, layer.post_attention_layernorm.weight):
+                fp.append((t.data_ptr(), t._version))
+        for t in (m.lm_head.weight, m.model.embed_tokens.weight, m.model.norm.weight):
+            fp.append((t.data_ptr(), t._version))
+        return tuple(fp)
+
+    def weights_changed(self, model=None) -> bool:
+        model = model if model is not None else self.model
+        if model is None or self._fingerprint is None:
+            return False
+        return self._weights_fingerprint(model) != self._fingerprint
+
+    def refresh_weights(self, model=None) -> None:
+        """Re-pack every projection from the model's CURRENT weights and re-bind the borrowed tensors (after
+        load_state_dict / in-place edits / a LoRA merge on the same model object).  The cached context is dropped."""
+        model = model if model is not None else self.model
+        if model is None:
+            raise _lib.LskError("refresh_weights: the model this engine was built from is gone")
+        if self.release_weights:
+            raise _lib.LskError("refresh_weights: this engine released the original weights (release_weights=True)")
+        with torch.cuda.device(self.device):
+            self._packed = []
+            self._globals = {}
+            self._pack_weights(model)
+            self._bind_weights()
+        self._fingerprint = self._weights_fingerprint(model)
+        self.reset()
+
     @property
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -208,6 +248,20 @@ class HipEngine:
         self._ck(self.lib.lsk_engine_create(ctypes.byref(self.cfg), self._buffers["ws"].data_ptr(), ws.value,
                                          self._buffers["kv"].data_ptr(), kv.value, ctypes.byref(handle)))
         self._handle = handle
+        self._bind_weights()
+        # a recreated engine keeps what the caller configured on the old one
+        for option, value in self._options.items():
+            self._ck(self.lib.lsk_engine_set_option(handle, option, value))
+        if self._block_table is not None and len(self._block_table) == self.max_ctx // self.page_size:
+            arr = _i32_array(self._block_table)
+            self._ck(self.lib.lsk_engine_set_block_table(handle, arr, len(self._block_table), self._stream))
+        else:
+            self._block_table = None         # a grown pool has more pages: back to the identity mapping
+        if self._profile:
+            self._ck(self.lib.lsk_engine_set_profile(handle, 1))
+
+    def _bind_weights(self) -> None:
+        handle = self._handle
         for i, packed in enumerate(self._packed):
             if packed is None:
                 continue
@@ -216,7 +270,8 @@ class HipEngine:
                                                 wdown.data_ptr(), n1.data_ptr(), n2.data_ptr()))
         g = self._globals
         self._ck(self.lib.lsk_engine_set_globals(handle, g["embed"].data_ptr(), g["final_norm"].data_ptr(),
-                                              g["lm_head"].data_ptr(), cos.data_ptr(), sin.data_ptr(), self.max_ctx))
+                                              g["lm_head"].data_ptr(), self._buffers["cos"].data_ptr(),
+                                              self._buffers["sin"].data_ptr(), self.max_ctx))
 
     def ensure_capacity(self, total_tokens: int, prompt_len: int) -> None:
         """Grow the KV pool / prompt buffer if a request needs more (context is lost)."""
@@ -251,6 +306,7 @@ class HipEngine:
     def set_block_table(self, table: Sequence[int]) -> None:
         arr = _i32_array(table)
         self._ck(self.lib.lsk_engine_set_block_table(self._handle, arr, len(table), self._stream))
+        self._block_table = [int(t) for t in table]
 
     # ------------------------------------------------------------------ fused fast paths
     def spec_step(self, input_ids: Sequence[int], num_speculations: int, exit_layer: int,
@@ -319,6 +375,25 @@ class HipEngine:
         return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
                           list(res.draft_tokens[:s]), list(res.verified_tokens[: s + 1]))
 
+    def spec_generate_sampled(self, prompt_ids: Sequence[int], num_speculations: int, exit_layer: int,
+                              eos_token_ids: Sequence[int], max_steps: int, temperature: float, top_k: int, top_p: float,
+                              seed: int, offset: int):
+        """Whole sample=True generation in one C-ABI call (lsk_spec_generate_sampled).  Same return as spec_generate."""
+        ids = _i32_array(prompt_ids)
+        eos, eos_arr = self._eos_array(eos_token_ids)
+        out = (ctypes.c_int32 * max_steps)()
+        sd = (ctypes.c_int32 * max_steps)()
+        sm = (ctypes.c_int32 * max_steps)()
+        n_out, tm, td, ns = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        scratch = self._sampling_scratch()
+        self._ck(self.lib.lsk_spec_generate_sampled(
+            self._handle, ids, len(prompt_ids), int(num_speculations), int(exit_layer), eos_arr, len(eos), int(max_steps),
+            float(temperature), int(top_k), float(top_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+            scratch.data_ptr(), scratch.numel(), out, ctypes.byref(n_out), ctypes.byref(tm), ctypes.byref(td), sd, sm,
+            ctypes.byref(ns), self._stream))
+        steps = [(sd[i], sm[i]) for i in range(ns.value)]
+        return list(out[: n_out.value]), tm.value, td.value, steps
+
     def ar_generate(self, input_ids: Sequence[int], layer_end: Optional[int], eos_token_ids: Sequence[int],
                     max_steps: int) -> List[int]:
         """Whole greedy autoregressive generation in one C-ABI call."""
@@ -355,6 +430,7 @@ class HipEngine:
 
     def set_option(self, option: int, value: int) -> None:
         self._ck(self.lib.lsk_engine_set_option(self._handle, option, value))
+        self._options[int(option)] = int(value)
 
     def run_head(self, buffer: int, row_base: int, m: int, logits: Optional[torch.Tensor] = None,
                  want_tokens: bool = True) -> Optional[List[int]]:
@@ -385,12 +461,28 @@ class HipEngine:
 
     def set_profile(self, enable: bool) -> None:
         self._ck(self.lib.lsk_engine_set_profile(self._handle, 1 if enable else 0))
+        self._profile = bool(enable)
 
     def get_profile(self):
         """(sum of the gate/up dispatch durations in ms, number of launches)."""
         ms, n = ctypes.c_float(0.0), ctypes.c_int32(0)
         self._ck(self.lib.lsk_engine_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    PROFILE_CLASSES = ("qkv", "attention", "o_proj", "gate_up", "down", "lm_head")
+
+    def get_profile_table(self):
+        """[{kernel, rows ("1" | ">1"), launches, ms, bytes}] for every decode-path kernel class since set_profile(True)."""
+        n = 12
+        ms, cnt, by = (ctypes.c_float * n)(), (ctypes.c_int32 * n)(), (ctypes.c_double * n)()
+        self._ck(self.lib.lsk_engine_get_profile_table(self._handle, n, ms, cnt, by))
+        out = []
+        for c, name in enumerate(self.PROFILE_CLASSES):
+            for multi in (0, 1):
+                i = 2 * c + multi
+                if cnt[i]:
+                    out.append({"kernel": name, "rows": ">1" if multi else "1", "launches": cnt[i], "ms": ms[i], "bytes": by[i]})
+        return out
 
     # bytes one launch of each projection streams from HBM (algorithmic: the packed weights once)
     def projection_bytes(self) -> dict:
@@ -408,9 +500,15 @@ class HipEngine:
 _ENGINES = None
 
 
-def get_engine(model, **kwargs) -> HipEngine:
+def get_engine(model, check_weights: bool = True, **kwargs) -> HipEngine:
     """The engine bound to ``model`` (built lazily on first use, reused across calls).  Kept in a weak
-    map, not on the module, so ``copy.deepcopy(model)`` and ``state_dict()`` never see it."""
+    map, not on the module, so ``copy.deepcopy(model)`` and ``state_dict()`` never see it.
+
+    The engine streams PACKED COPIES of the projections, so it must notice when the model's weights change under it
+    (load_state_dict, an in-place edit, a LoRA merge on the same object -- the reference always reads live weights):
+    with ``check_weights`` the (address, version) fingerprint taken at pack time is compared and the weights are
+    re-packed on a mismatch.  Keyword arguments that differ from the cached engine's are applied where that is possible
+    (capacity grows, target_wgs is an option) and reported otherwise."""
     global _ENGINES
     if _ENGINES is None:
         import weakref
@@ -419,4 +517,22 @@ def get_engine(model, **kwargs) -> HipEngine:
     if eng is None:
         eng = HipEngine(model, **kwargs)
         _ENGINES[model] = eng
+        return eng
+    if check_weights and eng.weights_changed(model):
+        eng.refresh_weights(model)
+    if kwargs:
+        import warnings
+        if kwargs.get("max_ctx", 0) > eng.max_ctx or kwargs.get("max_prompt", 0) > eng.max_prompt:
+            eng.ensure_capacity(kwargs.get("max_ctx", eng.max_ctx), kwargs.get("max_prompt", eng.max_prompt))
+        tw = kwargs.get("target_wgs")
+        if tw is not None and tw != eng.target_wgs:
+            eng.target_wgs = tw
+            eng.set_option(_lib.LSK_OPT_TARGET_WGS, tw)
+        for key in ("release_weights", "layer_range", "page_size"):
+            if key in kwargs and kwargs[key] is not None:
+                have = getattr(eng, key)
+                want = tuple(kwargs[key]) if key == "layer_range" else kwargs[key]
+                if have != want:
+                    warnings.warn(f"get_engine: {key}={kwargs[key]!r} ignored, the engine cached for this model was built "
+                                  f"with {key}={have!r}", RuntimeWarning, stacklevel=2)
     return eng

@@ -16,9 +16,13 @@ Execution paths:
         (`lsk_spec_generate` / `lsk_ar_generate`), speculation steps pipelined on the stream;
   step  greedy with a streamer or stopping criteria: ONE C-ABI call per speculation step (`lsk_spec_step`):
         draft loop, verify, ballot acceptance and KV rollback all stay on the device, one sync per step;
-  slow  logits processors, sampling or more than 15 speculations: the same kernels driven row-block by
-        row-block with the logits materialised as a tensor so the user's callables see what the reference
-        shows them.
+  sampled  `sample=True` without logits processors: the same two paths with every argmax replaced by a draw and the
+        prefix match by modified rejection sampling ON THE DEVICE (`lsk_spec_generate_sampled` / `lsk_spec_step_sampled`):
+        no logits row leaves HBM.  Parity with the reference is in distribution; the Philox stream is seeded from
+        torch's generator (`torch.manual_seed(s)` reproduces a generation).
+  slow  logits processors or more than 15 speculations: the same kernels driven row-block by row-block with the
+        logits materialised as a tensor so the user's callables see what the reference shows them (sampling, if
+        any, then happens on those logits with torch).
 """
 from __future__ import annotations
 
@@ -78,13 +82,16 @@ def _residual_distribution(p_verify: torch.Tensor, p_draft: torch.Tensor, eps: f
 
 
 class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
-    def __init__(self, engine_kwargs: Optional[dict] = None, fused_generate: bool = True, device_sampling: bool = False) -> None:
+    def __init__(self, engine_kwargs: Optional[dict] = None, fused_generate: bool = True, device_sampling: bool = True) -> None:
         self.engine_kwargs = engine_kwargs or {}
-        # device_sampling (opt-in, experimental in round 1): `sample=True` steps without logits processors run on the
-        # device (lsk_spec_step_sampled: top-k / top-p thresholds, Gumbel-max draws, rejection sampling) instead of
-        # materialising the logits for torch.  Seeded from torch.initial_seed(); one Philox offset per step.
+        # device_sampling (default): `sample=True` steps without logits processors run on the device (top-k / top-p
+        # thresholds, Gumbel-max draws, rejection sampling) instead of materialising the logits for torch.
+        # Seeding contract: key = torch.initial_seed(); the counter base of a generation is ONE 62-bit draw from
+        # torch's global generator at its start, step i adds i -- so torch.manual_seed(s) before generate_token_ids
+        # reproduces it, and two strategy instances (or two generations) never share a stream.
         self.device_sampling = device_sampling
-        self._sample_offset = 0
+        self._sample_base = None
+        self._sample_step = 0
         # fused_generate: greedy generations without processors / criteria / streamer run as ONE C-ABI call
         # (lsk_spec_generate: the loop of SSG:51-95 with the steps pipelined on the stream)
         self.fused_generate = fused_generate
@@ -99,13 +106,26 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         extra_rows = spec if spec > _lib.LSK_MAX_SPEC else 0      # long draft blocks live behind the prompt rows
         engine.ensure_capacity(len(input_ids) + generation_config.max_steps + spec + 2, len(input_ids) + extra_rows)
         engine.reset()                                            # past_key_values = None
-        if (self.fused_generate and not generation_config.sample and not logits_processors and not stopping_criteria
-                and streamer is None and spec <= _lib.LSK_MAX_SPEC and hasattr(engine, "spec_generate")
-                and "single_step_speculation" not in self.__dict__):
+        eos_token_ids = [t for t in eos_token_ids if t is not None]       # a tokenizer without an eos token (reference: `None in list` is just False)
+        device_sampled = bool(generation_config.sample and self.device_sampling and not logits_processors
+                              and spec <= _lib.LSK_MAX_SPEC and hasattr(engine, "spec_step_sampled"))
+        if device_sampled:
+            self._new_sample_stream()
+        if (self.fused_generate and not logits_processors and not stopping_criteria and streamer is None
+                and spec <= _lib.LSK_MAX_SPEC and "single_step_speculation" not in self.__dict__
+                and ((not generation_config.sample and hasattr(engine, "spec_generate"))
+                     or (device_sampled and hasattr(engine, "spec_generate_sampled")))):
             if not (1 <= generation_config.exit_layer < engine.num_layers):
                 raise ValueError(f"exit_layer={generation_config.exit_layer} must be in [1, {engine.num_layers})")
-            tokens, matches, drafts, self.last_steps = engine.spec_generate(
-                list(input_ids), spec, generation_config.exit_layer, eos_token_ids, generation_config.max_steps)
+            if generation_config.sample:
+                tokens, matches, drafts, self.last_steps = engine.spec_generate_sampled(
+                    list(input_ids), spec, generation_config.exit_layer, eos_token_ids, generation_config.max_steps,
+                    generation_config.temperature, generation_config.top_k, generation_config.top_p,
+                    torch.initial_seed(), self._sample_base)
+                self._sample_step += len(self.last_steps) + 1
+            else:
+                tokens, matches, drafts, self.last_steps = engine.spec_generate(
+                    list(input_ids), spec, generation_config.exit_layer, eos_token_ids, generation_config.max_steps)
             return GenerationStrategyResult(predicted_tokens=tokens, acceptance_rate=matches / drafts)
         past = None
         input_ids_list = list(input_ids)
@@ -138,6 +158,11 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         return GenerationStrategyResult(predicted_tokens=output_ids,
                                         acceptance_rate=total_draft_matches / total_generations)
 
+    def _new_sample_stream(self) -> None:
+        """Counter base of the Philox stream of one generation: one draw from torch's global generator."""
+        self._sample_base = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._sample_step = 0
+
     # ------------------------------------------------------------------------------ one step
     def single_step_speculation(self, model, input_ids: torch.Tensor, input_ids_list: List[int],
                                 output_ids: List[int], num_speculations: int, past_key_values,
@@ -154,11 +179,14 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         if not (1 <= exit_layer < engine.num_layers):
             raise ValueError(f"exit_layer={exit_layer} must be in [1, {engine.num_layers})")
         new_ids = [int(t) for t in input_ids[0].tolist()]
+        eos_token_ids = [t for t in eos_token_ids if t is not None]
         if (sample and self.device_sampling and not logits_processors and spec <= _lib.LSK_MAX_SPEC
                 and hasattr(engine, "spec_step_sampled")):
-            self._sample_offset += 1
+            if past_key_values is None or self._sample_base is None:
+                self._new_sample_stream()          # a step called on its own (the reference's tests do) starts a stream
             step = engine.spec_step_sampled(new_ids, spec, exit_layer, eos_token_ids, temperature, top_k, top_p,
-                                            torch.initial_seed(), self._sample_offset)
+                                            torch.initial_seed(), self._sample_base + self._sample_step)
+            self._sample_step += 1
         elif sample or logits_processors or spec > _lib.LSK_MAX_SPEC:
             # (more than 15 speculations do not fit the 16-row fused verify block: same kernels, rows walked in
             #  16-row passes from the host)
@@ -282,6 +310,7 @@ class HipAutoRegressiveGenerationStrategy(GenerationStrategy):
         engine = get_engine(model, **self.engine_kwargs)
         engine.ensure_capacity(len(input_ids) + generation_config.max_steps + 10, len(input_ids))
         engine.reset()
+        eos_token_ids = [t for t in eos_token_ids if t is not None]
         layer_end = generation_config.exit_layer if generation_config.exit_layer > 0 else engine.num_layers
         if layer_end > engine.num_layers:
             raise ValueError(f"exit_layer={layer_end} > num_layers={engine.num_layers}")

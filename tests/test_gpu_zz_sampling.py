@@ -1,7 +1,7 @@
-"""Device-side sampling (lsk_sample.h) against the draw-for-draw model in oracle/sampling_oracle.py.
-The two kernel checks were seen green on an MI355X at the end of round 1 and run by default.  The end-to-end check of
-lsk_spec_step_sampled (the orchestration around the two kernels) could not be run any more in that round: it stays
-behind LSK_EXPERIMENTAL=1, and so does the strategies' `device_sampling` switch, until it has been."""
+"""Device-side sampling (lsk_sample.h): the two kernels against the draw-for-draw model in
+oracle/sampling_oracle.py, and the whole `sample=True` path -- the strategies' default since round 2 -- against
+(a) distribution fixtures recorded from the UNMODIFIED reference (oracle/make_sampling_dist_golden.py, 256 seeds per case)
+and (b) the host-sampling path on the same GPU."""
 import ctypes
 import json
 import os
@@ -13,7 +13,7 @@ import torch
 from conftest import GOLDEN_DIR, build_case_model, load_golden
 
 pytestmark = pytest.mark.gpu
-experimental = pytest.mark.skipif(os.environ.get("LSK_EXPERIMENTAL") != "1", reason="opt-in: set LSK_EXPERIMENTAL=1")
+DIST = json.load(open(os.path.join(GOLDEN_DIR, "sampling", "dist.json")))
 
 CASES = json.load(open(os.path.join(GOLDEN_DIR, "sampling", "cases.json")))
 SHAPE_OF_VOCAB = {512: "tiny-mha", 1000: "tiny-gqa", 768: "tiny-d64"}
@@ -83,14 +83,73 @@ def test_accept_sampled_kernel_matches_the_model(gpu_device):
         assert r[4:4 + n] == drafts[:n] and r[4 + n] == r[2]
 
 
-@experimental
+def _tv(a, b):
+    na, nb = sum(a.values()), sum(b.values())
+    return 0.5 * sum(abs(a.get(k, 0) / na - b.get(k, 0) / nb) for k in set(a) | set(b))
+
+
+@pytest.mark.parametrize("idx", range(len(DIST)))
+def test_device_sampling_matches_the_unmodified_reference_in_distribution(gpu_device, idx):
+    """The HIP `sample=True` path (fused lsk_spec_generate_sampled AND one lsk_spec_step_sampled per step) over 256 seeds
+    against what the reference produced over 256 seeds on the same weights (bf16): acceptance rate, output length,
+    first- and second-token histograms, and no token outside the reference's own nucleus."""
+    from conftest import build_struct_model, load_struct
+    from layerskip_amd import GenerationConfig
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    case = DIST[idx]
+    rec = load_golden(case["fixture"]) if case["family"] == "legacy" else load_struct(case["fixture"])
+    model = (build_case_model(rec) if case["family"] == "legacy" else build_struct_model(rec)).to(gpu_device)
+    cfg = GenerationConfig(max_steps=case["max_steps"], exit_layer=case["exit_layer"], num_speculations=case["num_speculations"],
+                           sample=True, temperature=case["temperature"], top_k=case["top_k"], top_p=case["top_p"])
+    eos = [model.config.vocab_size]
+    n_runs = case["n_runs"]
+    ref_first = [{int(k): v for k, v in h.items()} for h in case["first_token_hist"]]
+    ref_second = [{int(k): v for k, v in h.items()} for h in case["second_token_hist"]]
+    merged = lambda hs: {k: hs[0].get(k, 0) + hs[1].get(k, 0) for k in set(hs[0]) | set(hs[1])}   # noqa: E731
+    nucleus = set(case["first_nucleus"])
+    # tokens whose reference probability is within a few bf16 ulp of the nucleus boundary may fall on either side
+    pmin = min(case["first_nucleus_probs"])
+    for fused in (True, False):
+        strat = HipSelfSpeculativeGenerationStrategy(fused_generate=fused)
+        assert strat.device_sampling
+        acc, lens, first, second = [], [], {}, {}
+        for i in range(n_runs):
+            torch.manual_seed(10_000 + i)
+            r = strat.generate_token_ids(model, list(rec["prompt"]), eos, cfg)
+            assert 0 < len(r.predicted_tokens) <= case["max_steps"]
+            acc.append(r.acceptance_rate)
+            lens.append(len(r.predicted_tokens))
+            first[r.predicted_tokens[0]] = first.get(r.predicted_tokens[0], 0) + 1
+            if len(r.predicted_tokens) > 1:
+                second[r.predicted_tokens[1]] = second.get(r.predicted_tokens[1], 0) + 1
+        mean = float(np.mean(acc))
+        se = (case["acceptance_std"] ** 2 / n_runs + float(np.var(acc)) / n_runs) ** 0.5
+        assert abs(mean - case["acceptance_mean"]) < 4 * se + 0.01, (fused, mean, case["acceptance_mean"], se)
+        assert abs(float(np.mean(lens)) - case["length_mean"]) < 0.5
+        outside = {t: c for t, c in first.items() if t not in nucleus}
+        assert sum(outside.values()) <= 0.02 * n_runs, (fused, "first tokens outside the reference's nucleus", outside, pmin)
+        # the reference's two half-samples differ from each other by pure sampling noise: that is the yardstick
+        for mine, halves, what in ((first, ref_first, "first"), (second, ref_second, "second")):
+            noise = _tv(halves[0], halves[1])
+            tv = _tv(mine, merged(halves))
+            assert tv < max(0.12, 1.25 * noise), (fused, what, tv, noise)
+        # reproducibility contract: the same torch seed gives the same generation
+        torch.manual_seed(10_000)
+        a = strat.generate_token_ids(model, list(rec["prompt"]), eos, cfg).predicted_tokens
+        torch.manual_seed(10_000)
+        b = strat.generate_token_ids(model, list(rec["prompt"]), eos, cfg).predicted_tokens
+        c = HipSelfSpeculativeGenerationStrategy(fused_generate=fused)
+        torch.manual_seed(10_000)
+        assert a == b == c.generate_token_ids(model, list(rec["prompt"]), eos, cfg).predicted_tokens
+
+
 def test_device_sampled_generation_matches_the_host_path_in_distribution(gpu_device):
     from layerskip_amd import GenerationConfig
     from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
     rec = load_golden("tiny_mha_s1")
     model = build_case_model(rec).to(gpu_device)
     kw = dict(max_steps=10, exit_layer=rec["exit_layer"], num_speculations=4, sample=True, temperature=0.12, top_k=0, top_p=0.9)
-    host, dev = HipSelfSpeculativeGenerationStrategy(), HipSelfSpeculativeGenerationStrategy(device_sampling=True)
+    host, dev = HipSelfSpeculativeGenerationStrategy(device_sampling=False), HipSelfSpeculativeGenerationStrategy(device_sampling=True)
     acc = {"host": [], "dev": []}
     first = {"host": {}, "dev": {}}
     n_runs = 120

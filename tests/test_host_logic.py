@@ -181,7 +181,7 @@ def test_engine_status_checks_use_the_engines_own_library():
             return b"stub says no"
 
     eng = object.__new__(HipEngine)
-    eng.lib, eng._handle = StubLib(), ctypes.c_void_p(None)
+    eng.lib, eng._handle, eng._options = StubLib(), ctypes.c_void_p(None), {}
     assert eng.kv_len == 41
     eng.set_option(3, 1)
     eng.lib.fail = True
