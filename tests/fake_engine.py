@@ -58,3 +58,59 @@ class FakeEngine:
         self.past = r.past
         self._kv_len += len(input_ids)
         return int(lo.decode_next_token_greedy(r.logits, token_idx=-1).item())
+
+
+class FullFakeEngine:
+    """CpuStageBackend (the building blocks the materialised-logits paths use) plus the fused `spec_step` / `ar_step`
+    entry points, built FROM those blocks: the complete HipEngine surface the strategies touch, on the CPU oracle
+    (fp32).  Lets the plugin run under the reference's own HuggingfaceLlamaGenerator without a GPU."""
+
+    def __new__(cls, model):
+        from cpu_stage_backend import CpuStageBackend
+
+        class _Impl(CpuStageBackend):
+            dtype = torch.float32
+
+            def spec_step(self, input_ids, num_speculations, exit_layer, eos):
+                ids, S, E, L = list(input_ids), int(num_speculations), int(exit_layer), self.num_layers
+                P = len(ids)
+                if P > 1:
+                    self.embed_rows(ids[:-1], 1, 0)
+                    self.run_bulk(P - 1, 0, E)
+                drafts, tok, j = [], ids[-1], 0
+                while True:
+                    self.embed_rows([tok], 0, j)
+                    self.run_layers(0, j, 1, P - 1 + j, 0, E)
+                    if j >= S:
+                        break
+                    tok = self.run_head(0, j, 1)[0]
+                    drafts.append(tok)
+                    j += 1
+                    if tok in eos:
+                        self.embed_rows([tok], 0, j)
+                        self.run_layers(0, j, 1, P - 1 + j, 0, E)
+                        break
+                td = len(drafts)
+                if P > 1:
+                    self.run_bulk(P - 1, E, L)
+                self.run_layers(0, 0, td + 1, P - 1, E, L)
+                verified = self.run_head(0, 0, td + 1)
+                n = 0
+                while n < td and drafts[n] == verified[n]:
+                    n += 1
+                self.set_kv_len(self.kv_len + P + n)
+                return StepResult(n, td, verified[n], self.kv_len, drafts[:n] + [verified[n]], drafts, verified)
+
+            def ar_step(self, input_ids, layer_end=None):
+                ids = list(input_ids)
+                P, le = len(ids), int(layer_end or self.num_layers)
+                if P > 1:
+                    self.embed_rows(ids[:-1], 1, 0)
+                    self.run_bulk(P - 1, 0, le)
+                self.embed_rows(ids[-1:], 0, 0)
+                self.run_layers(0, 0, 1, P - 1, 0, le)
+                tok = self.run_head(0, 0, 1)[0]
+                self.set_kv_len(self.kv_len + P)
+                return tok
+
+        return _Impl(model)

@@ -276,14 +276,16 @@ def _fill_pools(k, v, table, n_pages, n_kv, hd, dev, poison):
     return kpool.to(dev), vpool.to(dev)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("n_heads,n_kv,hd", [(4, 4, 128), (8, 2, 128), (8, 2, 64), (32, 8, 128)])
-@pytest.mark.parametrize("m,kv_len", [(1, 0), (1, 127), (7, 125), (16, 120), (16, 250), (7, 1140), (1, 1151), (16, 1136)])
+_GEOMS = [(1, 0), (1, 127), (7, 125), (16, 120), (16, 250), (7, 1140), (1, 1151), (16, 1136)]
+_ATTN_CASES = [(mode, nh, nkv, hd, m, kv) for mode in (0, 1, 2) for (nh, nkv, hd) in [(4, 4, 128), (8, 2, 128), (8, 2, 64)]
+               for (m, kv) in _GEOMS]
+_ATTN_CASES += [(mode, 32, 8, 128, m, kv) for mode in (0, 1, 2) for (m, kv) in [(7, 1140), (16, 120), (1, 127)]]   # llama3-8B heads
+
+
+@pytest.mark.parametrize("mode,n_heads,n_kv,hd,m,kv_len", _ATTN_CASES)
 def test_attention_matches_fp32_softmax(gpu_device, mode, n_heads, n_kv, hd, m, kv_len):
     """Rows at positions kv_len .. kv_len+m-1 (their own K/V already appended, as the engine does) against
     softmax_fp32(q k^T / sqrt(d) + causal) v in float64 on the SAME bf16 tensors.  Unwritten slots hold NaN."""
-    if n_heads == 32 and (m, kv_len) not in [(7, 1140), (16, 120), (1, 127)]:
-        pytest.skip("large head count: a subset of the geometries")
     lib, L = _lib()
     dev = gpu_device
     g = torch.Generator().manual_seed(n_heads * 131 + hd + 17 * m + kv_len)
