@@ -160,6 +160,26 @@ int lsk_ar_generate(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int3
                     const int32_t* eos_token_ids, int32_t n_eos, int32_t max_steps, int32_t* out_tokens,
                     int32_t* n_out, void* stream);
 
+/* ---- layer-range pipeline over several GPUs (one engine per rank, each bound to its own layer range) -------------
+ * The reference spreads models by accelerate's device_map="auto" (generate.py:62); here rank 0 owns layers [0, exit_layer)
+ * and a copy of the head and runs the whole draft loop (forward_early x S, llama_model_utils.py:213-276) as ONE
+ * asynchronous call; the other ranks run lsk_run_bulk / lsk_run_layers / lsk_run_head on the rows they receive.
+ *
+ * lsk_draft_block: [prompt rows through layers [0, E) when input_ids holds more than one id] then step rows
+ * row0 .. row0+n_rows-1, each through layers [0, E) at position kv_len + pos_off0 + j, a head + argmax after every row but
+ * the last (after the last too with head_last), each argmax embedded into the next row on the device.
+ * input_ids != NULL: a fresh block (row0 = 0, pos_off0 = prompt_len - 1, row 0 = embedding of the last id);
+ * input_ids == NULL: a continuation of the previous block (row0 already holds the embedding its last head produced) --
+ * what rank 0 does optimistically while a verify block is in flight.  Nothing is waited for. */
+int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows,
+                    int32_t pos_off0, int32_t exit_layer, int32_t head_last, void* stream);
+/* tokens of step rows [row0, row0 + n) (row 0 = the input token, row j = draft j): HOST int32[n]; synchronises */
+int lsk_get_row_tokens(lsk_engine* e, int32_t row0, int32_t n, int32_t* out, void* stream);
+/* move step rows (hidden rows + tokens) [src, src+n) down to [dst, dst+n), dst < src */
+int lsk_shift_rows(lsk_engine* e, int32_t src, int32_t dst, int32_t n, void* stream);
+/* byte offset of row `row_base` of a hidden-state buffer inside the workspace the caller handed to lsk_engine_create */
+int lsk_rows_offset(lsk_engine* e, int32_t buffer, int32_t row_base, size_t* out_offset);
+
 /* ---- building blocks (slow path with logits processors / sampling, and kernel parity tests) -- */
 
 /* h[buffer][row_base + i] = embed_tokens(ids[i])  (llama_model_utils.py:182,242,310).

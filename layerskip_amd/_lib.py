@@ -69,6 +69,10 @@ PROTOTYPES = {
     "lsk_ar_step": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, POINTER(c_int32), c_void_p]),
     "lsk_ar_generate": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, POINTER(c_int32), c_int32, c_int32,
                                   POINTER(c_int32), POINTER(c_int32), c_void_p]),
+    "lsk_draft_block": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_get_row_tokens": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32), c_void_p]),
+    "lsk_shift_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_rows_offset": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_size_t)]),
     "lsk_embed_rows": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
     "lsk_run_layers": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "lsk_run_bulk": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -1242,6 +1242,76 @@ extern "C" int lsk_ar_generate(lsk_engine* e, const int32_t* input_ids, int32_t 
     return 0;
 }
 
+// ---- layer-range pipeline: the rank-0 half of a step as one asynchronous call -------------------
+// The device-resident draft loop of enqueue_step without the verify: rank 0 of a layer pipeline owns layers [0, E)
+// and a copy of the head, drafts here, and streams the rows to the ranks that own the late layers.
+extern "C" int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows, int32_t pos_off0,
+                               int32_t exit_layer, int32_t head_last, void* stream) {
+    LSK_TRY(ready(e));
+    hipStream_t st = (hipStream_t)stream;
+    const lsk_config& c = e->cfg;
+    const int P = prompt_len, E = exit_layer;
+    if (E < 1 || E > c.num_layers) return lsk_fail("exit_layer %d out of range 1..%d", E, c.num_layers);
+    LSK_TRY(layers_bound(e, 0, E));
+    if (row0 < 0 || n_rows < 1 || row0 + n_rows + (head_last ? 1 : 0) > LSK_MAX_ROWS + (head_last ? 1 : 0) || row0 + n_rows > LSK_MAX_ROWS)
+        return lsk_fail("lsk_draft_block: rows [%d,%d) exceed the %d-row step buffer", row0, row0 + n_rows, LSK_MAX_ROWS);
+    if (head_last && row0 + n_rows >= LSK_MAX_ROWS) return lsk_fail("lsk_draft_block: no row left for the last head's token");
+    if (pos_off0 < 0 || e->kv_len_host + pos_off0 + n_rows > c.max_ctx) return lsk_fail("lsk_draft_block: positions exceed max_ctx");
+    const int* kvp = &e->state->kv_len;
+    if (input_ids != nullptr) {
+        if (P < 1 || P - 1 > c.max_prompt) return lsk_fail("prompt_len %d out of range (max_prompt %d)", P, c.max_prompt);
+        if (row0 != 0 || pos_off0 != P - 1) return lsk_fail("lsk_draft_block: a block that starts from host ids starts at row 0, position P-1");
+        LSK_TRY(check_ids(e, input_ids, P));
+        if (P > 1) HIP_OK(hipMemcpyAsync(e->bulk_ids, input_ids, sizeof(int) * (P - 1), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(e->row_tokens, input_ids + (P - 1), sizeof(int), hipMemcpyHostToDevice, st));
+        e->next_token_host = -1;
+        if (P > 1) {
+            LSK_TRY(embed_rows_dev(e, e->bulk_ids, P - 1, e->hbulk, st));
+            LSK_TRY(run_bulk(e, P - 1, kvp, 0, E, st));
+        }
+        LSK_TRY(embed_rows_dev(e, e->row_tokens, 1, e->hrow, st));
+    }   // else: row0 was embedded by the head of the previous block (a continuation)
+    for (int j = 0; j < n_rows; ++j) {
+        elem_t* xr = e->hrow + (size_t)(row0 + j) * c.hidden;
+        LSK_TRY(run_layers(e, xr, 1, kvp, pos_off0 + j, 0, E, st));
+        if (j + 1 < n_rows || head_last) LSK_TRY(run_head(e, xr, 1, nullptr, 0, e->row_tokens + row0 + j + 1, st, xr + c.hidden));
+    }
+    return 0;
+}
+
+extern "C" int lsk_get_row_tokens(lsk_engine* e, int32_t row0, int32_t n, int32_t* out, void* stream) {
+    if (!e || !out || row0 < 0 || n < 1 || row0 + n > LSK_MAX_ROWS + 1) return lsk_fail("lsk_get_row_tokens: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemcpyAsync(e->host_result, e->row_tokens + row0, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    memcpy(out, e->host_result, sizeof(int) * n);
+    return 0;
+}
+
+// rows [src, src+n) of the step buffer (hidden rows and their tokens) -> rows [dst, dst+n), dst < src
+extern "C" int lsk_shift_rows(lsk_engine* e, int32_t src, int32_t dst, int32_t n, void* stream) {
+    if (!e || n < 1 || dst < 0 || src <= dst || src + n > LSK_MAX_ROWS + 1) return lsk_fail("lsk_shift_rows: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t row_bytes = (size_t)e->cfg.hidden * 2;
+    const int nr = src + n > LSK_MAX_ROWS ? LSK_MAX_ROWS - src : n;      // hidden rows (the token array has one more entry)
+    for (int i = 0; i < nr; ++i)      // ascending: dst < src, regions may overlap
+        HIP_OK(hipMemcpyAsync((char*)e->hrow + (size_t)(dst + i) * row_bytes, (char*)e->hrow + (size_t)(src + i) * row_bytes, row_bytes,
+                              hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < n; ++i)
+        HIP_OK(hipMemcpyAsync(e->row_tokens + dst + i, e->row_tokens + src + i, sizeof(int), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// Byte offset of a hidden-state row inside the caller-owned workspace: the host wraps rows as zero-copy tensors
+// (point-to-point send / recv straight from / into the engine's buffers).
+extern "C" int lsk_rows_offset(lsk_engine* e, int32_t buffer, int32_t row_base, size_t* out_offset) {
+    if (!e || !out_offset) return lsk_fail("lsk_rows_offset: null pointer");
+    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
+    if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base >= cap) return lsk_fail("lsk_rows_offset: rows out of range");
+    *out_offset = (size_t)((unsigned char*)buf_rows(e, buffer, row_base) - e->ws);
+    return 0;
+}
+
 // ---- building blocks -------------------------------------------------------------------------------
 extern "C" int lsk_embed_rows(lsk_engine* e, const int32_t* ids, int32_t n, int32_t buffer, int32_t row_base, void* stream) {
     LSK_TRY(ready(e));

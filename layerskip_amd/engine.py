@@ -412,6 +412,33 @@ class HipEngine:
                                    ctypes.byref(tok), self._stream))
         return tok.value
 
+    # ------------------------------------------------------------------ layer-range pipeline (rank-0 half of a step)
+    def draft_block(self, input_ids: Optional[Sequence[int]], row0: int, n_rows: int, pos_off0: int, exit_layer: int,
+                    head_last: bool = False) -> None:
+        """Asynchronous device-resident draft loop over step rows [row0, row0 + n_rows) (lsk_draft_block)."""
+        if input_ids is None:
+            ids, n = None, 1
+        else:
+            ids, n = _i32_array(input_ids), len(input_ids)
+        self._ck(self.lib.lsk_draft_block(self._handle, ids, n, int(row0), int(n_rows), int(pos_off0), int(exit_layer),
+                                       1 if head_last else 0, self._stream))
+
+    def row_tokens(self, row0: int, n: int) -> List[int]:
+        out = (ctypes.c_int32 * n)()
+        self._ck(self.lib.lsk_get_row_tokens(self._handle, int(row0), int(n), out, self._stream))
+        return list(out)
+
+    def shift_rows(self, src: int, dst: int, n: int) -> None:
+        self._ck(self.lib.lsk_shift_rows(self._handle, int(src), int(dst), int(n), self._stream))
+
+    def rows_view(self, buffer: int, row_base: int, m: int) -> torch.Tensor:
+        """Rows of a hidden-state buffer as a ZERO-COPY tensor over the engine's workspace ([m, hidden], model dtype):
+        point-to-point send / recv go straight from / into the engine's buffers on the current stream."""
+        off = ctypes.c_size_t(0)
+        self._ck(self.lib.lsk_rows_offset(self._handle, buffer, row_base, ctypes.byref(off)))
+        nbytes = m * self.hidden * 2
+        return self._buffers["ws"][off.value: off.value + nbytes].view(self.dtype).view(m, self.hidden)
+
     # ------------------------------------------------------------------ building blocks
     def embed_rows(self, ids: Sequence[int], buffer: int, row_base: int) -> None:
         arr = _i32_array(ids)

@@ -292,7 +292,7 @@ def build_structured_model(config: transformers.LlamaConfig, seed: int = 0, exit
     jump = max(2, int(k["jump"]))
     pos_of = {t: i for i, t in enumerate(cyc)}
     sigma = {t: cyc[(pos_of[t] + jump) % n_act] for t in cyc}
-    n_over = max(1, int(round(k["override_frac"] * n_act)))
+    n_over = max(1, int(round(k["override_frac"] * n_act))) if k["override_frac"] > 0 else 0     # 0: the full model agrees with its early exit
     override = [cyc[i] for i in torch.randperm(n_act, generator=g)[:n_over].tolist()]
     early_layer, late_layer = 0, exit_layer
     kg = k["key_gain"] * rs          # gate/up rows: kg * u  ->  pre-activation key_gain * cos(x, u)
@@ -326,7 +326,7 @@ def build_structured_model(config: transformers.LlamaConfig, seed: int = 0, exit
             wg[:n_act] = kg * keys
             wu[:n_act] = kg * keys
             wd[:, :n_act] = (k["early_gain"] / act) * vals.t()
-        if idx == late_layer:
+        if idx == late_layer and n_over:
             keys = embed[[pi[t] for t in override]]             # key on the early path's prediction u_pi(t)
             vals = embed[[sigma[t] for t in override]]
             wg[:n_over] = kg * keys

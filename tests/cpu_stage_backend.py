@@ -23,6 +23,7 @@ class CpuStageBackend:
         self.buf = {0: torch.zeros(16, self.hidden), 1: torch.zeros(max_rows, self.hidden)}
         self.kv = [None] * self.num_layers
         self._kv_len = 0
+        self._row_tokens = [0] * 18
 
     def _partial_oracle(self, model):
         # only this rank's layers are materialised; borrow them, leave the rest as None
@@ -95,6 +96,36 @@ class CpuStageBackend:
         if logits is not None:
             logits[:m, : self.vocab] = lg
         return lg.argmax(-1).tolist() if want_tokens else None
+
+    # ---- layer-range pipeline surface (HipEngine.draft_block / row_tokens / shift_rows / rows_view)
+    def draft_block(self, input_ids, row0, n_rows, pos_off0, exit_layer, head_last=False):
+        E = int(exit_layer)
+        if input_ids is not None:
+            ids = list(input_ids)
+            P = len(ids)
+            assert row0 == 0 and pos_off0 == P - 1
+            if P > 1:
+                self.embed_rows(ids[:-1], 1, 0)
+                self.run_bulk(P - 1, 0, E)
+            self._row_tokens[0] = ids[-1]
+            self.embed_rows(ids[-1:], 0, 0)
+        for j in range(n_rows):
+            self.run_layers(0, row0 + j, 1, pos_off0 + j, 0, E)
+            if j + 1 < n_rows or head_last:
+                tok = self.run_head(0, row0 + j, 1)[0]
+                self._row_tokens[row0 + j + 1] = tok
+                self.embed_rows([tok], 0, row0 + j + 1)
+
+    def row_tokens(self, row0, n):
+        return list(self._row_tokens[row0:row0 + n])
+
+    def shift_rows(self, src, dst, n):
+        nr = min(n, 16 - src)
+        self.buf[0][dst:dst + nr] = self.buf[0][src:src + nr].clone()
+        self._row_tokens[dst:dst + n] = self._row_tokens[src:src + n]
+
+    def rows_view(self, buffer, row_base, m):
+        return self.buf[buffer][row_base:row_base + m]
 
     def read_rows(self, buffer, row_base, m):
         return self.buf[buffer][row_base:row_base + m].to(torch.bfloat16).clone()

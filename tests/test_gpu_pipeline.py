@@ -1,0 +1,73 @@
+"""The layer-range pipeline with REAL HIP engines: two / three processes sharing the one GPU of the box (gloo for the
+host-side exchange; on a multi-GPU node the same protocol runs over RCCL with the rows sent straight from the engines'
+buffers), against the single-process fused engine.  Covers the device-resident draft block, the header protocol and
+the optimistic continuation (always right on a checkpoint whose drafts are all accepted, discarded on one that rejects)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, queue, override_frac):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from layerskip_amd import synthetic
+        from layerskip_amd.engine import HipEngine
+        from layerskip_amd.pipeline import PipelineSpeculativeDecoder, plan_partition
+        dev = torch.device("cuda:0")
+        cfg = synthetic.make_config("tiny-gqa")
+        E, S = 3, 6
+        part = plan_partition(cfg.num_hidden_layers, E, world)
+        model = synthetic.build_structured_model(cfg, seed=4, exit_layer=E, override_frac=override_frac, layer_range=part[rank], device=dev)
+        eng = HipEngine(model, max_ctx=512, max_prompt=64, layer_range=part[rank])
+        dec = PipelineSpeculativeDecoder(eng, rank, world, part, E, comm_device=torch.device("cpu"))
+        prompt = synthetic.make_struct_prompt(model.struct_program, 19, 2)
+        res = dec.generate(prompt if rank == 0 else None, [cfg.vocab_size], 40, S)
+        if rank == 0:
+            queue.put((res.predicted_tokens, res.acceptance_rate, res.steps, dec.stats()))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,override_frac", [(2, 0.0), (2, 0.3), (3, 0.3)])
+def test_pipeline_of_hip_engines_equals_the_fused_engine(gpu_device, world, override_frac):
+    from layerskip_amd import GenerationConfig, synthetic
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, queue, override_frac)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tokens, rate, steps, stats = queue.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = synthetic.make_config("tiny-gqa")
+    model = synthetic.build_structured_model(cfg, seed=4, exit_layer=3, override_frac=override_frac, device=gpu_device)
+    prompt = synthetic.make_struct_prompt(model.struct_program, 19, 2)
+    strat = HipSelfSpeculativeGenerationStrategy()
+    want = strat.generate_token_ids(model, prompt, [cfg.vocab_size],
+                                    GenerationConfig(max_steps=40, exit_layer=3, num_speculations=6, sample=False))
+    assert tokens == want.predicted_tokens
+    assert [tuple(s) for s in steps] == [tuple(s) for s in strat.last_steps]
+    assert rate == want.acceptance_rate
+    if override_frac == 0.0:
+        assert stats["optimistic_attempts"] >= 3 and stats["optimistic_hits"] == stats["optimistic_attempts"]
+    else:
+        assert stats["optimistic_attempts"] > stats["optimistic_hits"]

@@ -19,6 +19,34 @@ def _free_port():
     return port
 
 
+def _struct_worker(rank, world, port, queue, override_frac, optimistic):
+    """Structured checkpoint: override_frac = 0 -> every draft accepted and every optimistic guess right (the
+    continuation path runs on every step); 0.3 -> rejections force the continuation to be discarded."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_stage_backend import CpuStageBackend
+        from layerskip_amd import synthetic
+        from layerskip_amd.pipeline import PipelineSpeculativeDecoder, plan_partition
+        cfg = synthetic.make_config("tiny-gqa")
+        E, S = 3, 6
+        part = plan_partition(cfg.num_hidden_layers, E, world)
+        model = synthetic.build_structured_model(cfg, seed=4, exit_layer=E, override_frac=override_frac, layer_range=part[rank]).float()
+        be = CpuStageBackend(model, layer_range=part[rank])
+        dec = PipelineSpeculativeDecoder(be, rank, world, part, E, optimistic=optimistic)
+        prompt = synthetic.make_struct_prompt(model.struct_program, 19, 2)
+        res = dec.generate(prompt if rank == 0 else None, [cfg.vocab_size], 40, S)
+        if rank == 0:
+            queue.put((res.predicted_tokens, res.acceptance_rate, res.steps, dec.stats()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, queue):
     import sys
     sys.path.insert(0, ROOT)
@@ -85,6 +113,41 @@ def test_pipeline_matches_single_process(world):
         want_eos = lo.self_speculative_generate(om, prompt, [eos], 18, 2, 4)
     assert tokens_eos == want_eos.predicted_tokens
     assert eos not in tokens_eos
+
+
+@pytest.mark.parametrize("world,override_frac,optimistic", [(2, 0.0, True), (3, 0.3, True), (2, 0.3, False)])
+def test_optimistic_overlap_is_output_preserving(world, override_frac, optimistic):
+    """Rank 0 drafts step k+1 while step k's verify block is in flight.  With a checkpoint whose drafts are always
+    accepted the continuation is used on every step; with one that rejects, it is discarded -- tokens and the per-step
+    (num_drafts, num_matches) trace equal the single-process oracle in both."""
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_struct_worker, args=(r, world, port, queue, override_frac, optimistic)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tokens, rate, steps, stats = queue.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from layerskip_amd import synthetic
+    from oracle import llama_oracle as lo
+    cfg = synthetic.make_config("tiny-gqa")
+    model = synthetic.build_structured_model(cfg, seed=4, exit_layer=3, override_frac=override_frac).float()
+    prompt = synthetic.make_struct_prompt(model.struct_program, 19, 2)
+    with torch.inference_mode():
+        want = lo.self_speculative_generate(lo.OracleModel.from_hf(model), prompt, [cfg.vocab_size], 40, 3, 6)
+    assert tokens == want.predicted_tokens
+    assert [list(s) for s in steps] == [[s.num_drafts, s.num_matches] for s in want.steps]
+    assert rate == pytest.approx(want.acceptance_rate, abs=1e-12)
+    if not optimistic:
+        assert stats["optimistic_attempts"] == 0
+    elif override_frac == 0.0:
+        assert want.acceptance_rate == 1.0
+        assert stats["optimistic_attempts"] >= 3 and stats["optimistic_hits"] == stats["optimistic_attempts"]
+    else:
+        assert 0 < want.acceptance_rate < 1.0
+        assert stats["optimistic_attempts"] > stats["optimistic_hits"]          # a forced rejection discarded a continuation
 
 
 def test_partition_plan():
