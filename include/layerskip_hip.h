@@ -14,7 +14,10 @@
  *     human readable message for the calling thread.  Nothing throws, nothing aborts.
  *   - device memory is OWNED BY THE CALLER (PyTorch-ROCm tensors used as storage): the caller
  *     allocates the workspace, the KV page pool and the packed weight buffers with the sizes the
- *     `lsk_*_bytes` functions report and keeps them alive for the life of the engine.
+ *     `lsk_*_bytes` functions report and keeps them alive for the life of the engine.  The KV pool needs NO
+ *     initialisation: slots that were never written may hold any bit pattern (NaN / Inf included); the
+ *     attention kernels select masked scores away and zero the V elements behind the last visible key.
+ *     The workspace must be zero-filled once before lsk_engine_create (arrival tickets live in it).
  *   - bf16 everywhere a dtype is not stated; fp32 accumulation inside every kernel.
  *   - rows: at most LSK_MAX_ROWS (16) token rows per kernel pass (draft: 1, verify:
  *     num_speculations+1); longer inputs (prompt prefill) are walked in 16-row chunks by the
@@ -201,10 +204,6 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
 #define LSK_OPT_TARGET_WGS 2      /* workgroups per skinny projection launch (default 256) */
 #define LSK_OPT_FUSED_ATTN 3      /* 1 (default): page partials combined in-launch by the last arriver; 0: second kernel */
 #define LSK_OPT_FLASH_PREFILL 5   /* 1 (default): prompt rows use the flash-shaped prefill attention kernel; 0: 16-row decode passes */
-#define LSK_OPT_FUSED_OPROJ 4     /* 1: attention and o_proj as one role-pipelined launch (rows <= 8); default 0 (measured neutral) */
-#define LSK_OPT_CHAIN 6           /* 1: o_proj -> gate/up -> down [-> next layer's q/k/v] as ONE resident grid with in-launch
-                                     phase hand-offs (lsk_chain.h); bit-identical; default 0 (measured slower than launch
-                                     boundaries: DESIGN.md 3.3) */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
 /* ---- sampling on the device (sample=True; GenerationConfig temperature / top_k / top_p, generator_base.py:35-44) ----
  * Both kernels are checked draw for draw against the oracle's model of them, and lsk_spec_step_sampled end to end against the

@@ -19,8 +19,6 @@
 #include "lsk_common.h"
 #include "lsk_gemm.h"
 #include "lsk_gemm_big.h"
-#include "lsk_fused.h"
-#include "lsk_chain.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -209,17 +207,9 @@ struct lsk_engine {
     elem_t* attn = nullptr;       // [16][n_heads*hd]
     elem_t* act = nullptr;        // [16][I]
     float* attn_part = nullptr;   // [n_heads][n_pages][16][hd + 2] split-KV partials
-    int* attn_cnt = nullptr;      // [n_heads] arrival tickets of the in-launch combine, then heads_done
-    int* heads_done = nullptr;    // monotonic: += n_heads per fused attention+o_proj launch
-    int heads_epoch = 0;          // fused launches since the last reset
+    int* attn_cnt = nullptr;      // [n_heads / HW] arrival tickets of the in-launch combine (self-resetting)
     bool fused_attn = true;
     bool flash_prefill = true;    // prompt rows: one flash-shaped attention launch per layer instead of rows/16 decode launches
-    bool fused_oproj = false;     // measured neutral at 7B (15.7 us fused vs 8.9 + 6.3 + gap): the seam is a latency chain
-    bool chain = false;           // LSK_OPT_CHAIN: o_proj -> gate/up -> down [-> next QKV] as one resident grid (lsk_chain.h)
-    int* chain_ctr = nullptr;     // [3][LSK_CHAIN_CTR_STRIDE] phase counters
-    int chain_base = 0;           // value of the counters before the next chained launch
-    int n_cus = 0;                // compute units of the device (co-residency bound of a chained grid)
-    bool chain_attr_done = false;
     elem_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]
     elem_t* kv_pool = nullptr;
     size_t kv_layer_elems = 0;    // elements per layer (K and V)
@@ -288,7 +278,7 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.attn = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
     L.act = take(2 * (size_t)LSK_MAX_ROWS * c->intermediate);
     L.attn_part = take(sizeof(float) * (size_t)c->n_heads * L.n_pages * LSK_MAX_ROWS * (c->head_dim + 2));
-    L.attn_cnt = take(sizeof(int) * (size_t)(c->n_heads + 16 + 3 * LSK_CHAIN_CTR_STRIDE));   // tickets per head + heads_done + chain phase counters
+    L.attn_cnt = take(sizeof(int) * (size_t)(c->n_heads + 16));   // arrival tickets per head column
     L.xn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->hidden);
     L.q_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
     L.attn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
@@ -358,10 +348,6 @@ static int init_kernel_attrs() {
     LSK_TRY((set_gemm_attr<PRO_RMS, EPI_SWIGLU>()));
     LSK_TRY((set_gemm_attr<PRO_RMS, EPI_QKV>()));
     LSK_TRY((set_gemm_attr<PRO_RMS, EPI_HEAD>()));
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_attn_oproj_kernel<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
     if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
     return 0;
 }
@@ -402,8 +388,6 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->act = (elem_t*)(e->ws + L.act);
     e->attn_part = (float*)(e->ws + L.attn_part);
     e->attn_cnt = (int*)(e->ws + L.attn_cnt);
-    e->heads_done = e->attn_cnt + cfg->n_heads;
-    e->chain_ctr = e->attn_cnt + cfg->n_heads + 16;
     e->xn_bulk = (elem_t*)(e->ws + L.xn_bulk);
     e->q_bulk = (elem_t*)(e->ws + L.q_bulk);
     e->attn_bulk = (elem_t*)(e->ws + L.attn_bulk);
@@ -420,7 +404,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     hipError_t err = hipMemcpy(e->block_table, table.data(), sizeof(int) * L.n_pages, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
     if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
-    if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * (cfg->n_heads + 16 + 3 * LSK_CHAIN_CTR_STRIDE));
+    if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * (cfg->n_heads + 16));
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 128, hipHostMallocDefault);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[0], hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[1], hipEventDisableTiming);
@@ -475,9 +459,7 @@ static int set_kv_len(lsk_engine* e, int kv_len, bool add, hipStream_t st) {
 
 extern "C" int lsk_engine_reset(lsk_engine* e, void* stream) {
     if (!e) return lsk_fail("null engine");
-    HIP_OK(hipMemsetAsync(e->attn_cnt, 0, sizeof(int) * (e->cfg.n_heads + 16 + 3 * LSK_CHAIN_CTR_STRIDE), (hipStream_t)stream));
-    e->heads_epoch = 0;
-    e->chain_base = 0;
+    HIP_OK(hipMemsetAsync(e->attn_cnt, 0, sizeof(int) * (e->cfg.n_heads + 16), (hipStream_t)stream));
     return set_kv_len(e, 0, false, (hipStream_t)stream);
 }
 
@@ -579,7 +561,11 @@ static int attn_params(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     pages = last_pos / LSK_ATTN_PAGE + 1;
     if (pages > e->n_pages) return lsk_fail("attention reaches page %d of %d", pages, e->n_pages);
     sp.n_pages = pages;
-    sp.heads_done = nullptr;
+    // query heads of one KV head that share a workgroup (and one fetch of the page): as many as fit the 16 MFMA rows
+    int hw = 1;
+    while (hw * 2 <= sp.group && hw * 2 * m <= LSK_MAX_ROWS && sp.group % (hw * 2) == 0) hw *= 2;
+    sp.heads_per_wg = hw;
+    sp.inv_m = (256 + m - 1) / m;
     return 0;
 }
 
@@ -589,7 +575,7 @@ static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     AttnSplitParams sp;
     int pages = 0;
     LSK_TRY(attn_params(e, q, out, kpool, vpool, m, pos_off, sp, pages));
-    const dim3 grid(c.n_heads, pages), block(LSK_ATTN_THREADS);
+    const dim3 grid(c.n_heads / sp.heads_per_wg, pages), block(LSK_ATTN_THREADS);
     hipEvent_t ea = nullptr, eb = nullptr;
     // algorithmic bytes: K and V of every key in reach, once (GQA: each KV head once)
     LSK_TRY(profile_pair(e, LSK_PROF_ATTN, m, 2.0 * 2.0 * c.n_kv_heads * hd * (double)(e->kv_len_host + pos_off + m), &ea, &eb));
@@ -609,141 +595,16 @@ static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     return 0;
 }
 
-// attention + o_proj/residual of one layer as ONE role-pipelined launch (lsk_fused.h); m <= 8
-static int launch_attn_oproj(lsk_engine* e, const elem_t* kpool, const elem_t* vpool, const LayerWeights& lw, elem_t* x, int m,
-                             int pos_off, hipStream_t st) {
-    const lsk_config& c = e->cfg;
-    const int hd = c.head_dim;
-    const int qdim = c.n_heads * hd;
-    AttnSplitParams sp;
-    int pages = 0;
-    LSK_TRY(attn_params(e, e->qbuf, e->attn, kpool, vpool, m, pos_off, sp, pages));
-    sp.heads_done = e->heads_done;
-    GemmParams p{};
-    p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
-    p.wp = lw.wo; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
-    p.h = x; p.ldh = c.hidden;
-    p.tiles_per_wg = tiles_per_wg(p.n_tiles, e->target_wgs);
-    const int gemm_grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
-    const int n_attn = c.n_heads * pages;
-    size_t lds = lsk_gemm_lds_bytes(m, p.K);
-    const size_t attn_lds = hd == 128 ? (size_t)lsk_attn_lds_bytes<128>() : (size_t)lsk_attn_lds_bytes<64>();
-    if (attn_lds > lds) lds = attn_lds;
-    if (lds > kMaxGemmLds) return lsk_fail("fused attention+o_proj LDS %zu exceeds %zu", lds, kMaxGemmLds);
-    const int target = (e->heads_epoch + 1) * c.n_heads;
-    const dim3 grid(n_attn + gemm_grid), block(LSK_THREADS);
-#define LSK_FUSED_CASE(HD, MB) hipLaunchKernelGGL((lsk_attn_oproj_kernel<HD, MB>), grid, block, lds, st, sp, p, n_attn, c.n_heads, (const int*)e->heads_done, target)
-    if (hd == 128) { if (m == 1) LSK_FUSED_CASE(128, 1); else LSK_FUSED_CASE(128, 8); }
-    else { if (m == 1) LSK_FUSED_CASE(64, 1); else LSK_FUSED_CASE(64, 8); }
-#undef LSK_FUSED_CASE
-    HIP_OK(hipGetLastError());
-    e->heads_epoch += 1;
-    return 0;
-}
-
-// o_proj -> gate/up -> down [-> QKV of layer l + 1] of one layer as ONE resident grid (lsk_chain.h).  Returns with
-// *chained = false (nothing launched) when the shape does not allow it: the caller then uses the separate launches.
-static int launch_chain(lsk_engine* e, int l, bool with_next_qkv, elem_t* x, int m, const int* base_ptr, int pos_off, hipStream_t st,
-                        bool* chained) {
-    const lsk_config& c = e->cfg;
-    const int qdim = c.n_heads * c.head_dim;
-    const int kvdim = c.n_kv_heads * c.head_dim;
-    *chained = false;
-    if (e->n_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        HIP_OK(hipGetDevice(&dev));
-        HIP_OK(hipGetDeviceProperties(&prop, dev));
-        e->n_cus = prop.multiProcessorCount;
-    }
-    const LayerWeights& lw = e->layers[l];
-    ChainParams cp{};
-    auto plan = [&](GemmParams& p, int unit, int* grid) {
-        p.tiles_per_wg = tiles_per_wg(p.n_tiles / unit, e->target_wgs) * unit;
-        *grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
-    };
-    {   // o_proj + residual
-        GemmParams& p = cp.o;
-        p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
-        p.wp = lw.wo; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
-        p.h = x; p.ldh = c.hidden;
-        plan(p, 1, &cp.grid_o);
-    }
-    {   // post-attention RMSNorm -> gate/up -> SiLU * up
-        GemmParams& p = cp.gu;
-        p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
-        p.wp = lw.wgu; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
-        p.norm_w = lw.norm2; p.eps = c.rms_eps; p.act = e->act; p.ldact = c.intermediate;
-        plan(p, 2, &cp.grid_gu);
-    }
-    {   // down_proj + residual
-        GemmParams& p = cp.down;
-        p.x = e->act; p.ldx = c.intermediate; p.M = m; p.K = c.intermediate; p.N = c.hidden; p.n_tiles = p.N / 16;
-        p.wp = lw.wdown; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
-        p.h = x; p.ldh = c.hidden;
-        plan(p, 1, &cp.grid_down);
-    }
-    int grid = cp.grid_o > cp.grid_gu ? cp.grid_o : cp.grid_gu;
-    if (cp.grid_down > grid) grid = cp.grid_down;
-    size_t lds = lsk_gemm_lds_bytes(m, cp.down.K);
-    if (lsk_gemm_lds_bytes(m, cp.gu.K) > lds) lds = lsk_gemm_lds_bytes(m, cp.gu.K);
-    if (lsk_gemm_lds_bytes(m, cp.o.K) > lds) lds = lsk_gemm_lds_bytes(m, cp.o.K);
-    if (with_next_qkv) {   // next layer: input RMSNorm -> q/k/v -> RoPE -> KV append
-        const LayerWeights& nw = e->layers[l + 1];
-        elem_t* kpool = e->kv_pool + (size_t)(l + 1) * e->kv_layer_elems;
-        GemmParams& p = cp.qkv;
-        p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = qdim + 2 * kvdim; p.n_tiles = p.N / 16;
-        p.wp = nw.wqkv; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
-        p.norm_w = nw.norm1; p.eps = c.rms_eps;
-        p.q_out = e->qbuf; p.ldq = qdim; p.kpool = kpool; p.vpool = kpool + e->kv_half_elems; p.block_table = e->block_table;
-        p.page_size = c.page_size; p.n_heads = c.n_heads; p.n_kv = c.n_kv_heads; p.head_dim = c.head_dim;
-        p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin; p.kv_len = base_ptr; p.pos_off = pos_off;
-        plan(p, 1, &cp.grid_qkv);
-        if (cp.grid_qkv > grid) grid = cp.grid_qkv;
-        if (lsk_gemm_lds_bytes(m, p.K) > lds) lds = lsk_gemm_lds_bytes(m, p.K);
-    }
-    const GemmParams* all[4] = {&cp.o, &cp.gu, &cp.down, &cp.qkv};
-    for (int i = 0; i < (with_next_qkv ? 4 : 3); ++i)
-        if ((size_t)all[i]->n_tiles * 16 * (size_t)all[i]->K * 2 >= (size_t)LSK_OOB_OFFSET) return 0;   // caller falls back (and reports there)
-    // every workgroup must be resident at once, and the counters must not wrap inside one generation
-    if (grid > e->n_cus || lds > kMaxGemmLds || m > 16 || e->chain_base > (1 << 30)) return 0;
-    if (!e->chain_attr_done) {
-        HIP_OK(hipFuncSetAttribute((const void*)lsk_chain_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-        HIP_OK(hipFuncSetAttribute((const void*)lsk_chain_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-        HIP_OK(hipFuncSetAttribute((const void*)lsk_chain_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-        HIP_OK(hipFuncSetAttribute((const void*)lsk_chain_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-        HIP_OK(hipFuncSetAttribute((const void*)lsk_chain_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-        HIP_OK(hipFuncSetAttribute((const void*)lsk_chain_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-        e->chain_attr_done = true;
-    }
-    cp.counters = e->chain_ctr;
-    cp.base = e->chain_base;
-#define LSK_CHAIN_CASE(MB)                                                                                                   \
-    do {                                                                                                                     \
-        if (with_next_qkv) hipLaunchKernelGGL((lsk_chain_kernel<MB, true>), dim3(grid), dim3(LSK_THREADS), lds, st, cp);     \
-        else hipLaunchKernelGGL((lsk_chain_kernel<MB, false>), dim3(grid), dim3(LSK_THREADS), lds, st, cp);                  \
-    } while (0)
-    if (m == 1) LSK_CHAIN_CASE(1);
-    else if (m <= 8) LSK_CHAIN_CASE(8);
-    else LSK_CHAIN_CASE(16);
-#undef LSK_CHAIN_CASE
-    HIP_OK(hipGetLastError());
-    e->chain_base += grid;
-    *chained = true;
-    return 0;
-}
-
 // decoder layers [lb, le) in place over rows of `x` (positions *base_ptr + pos_off + i)
 static int run_layers(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st) {
     const lsk_config& c = e->cfg;
     const int qdim = c.n_heads * c.head_dim;
     const int kvdim = c.n_kv_heads * c.head_dim;
-    bool qkv_done = false;      // the chained launch of layer l - 1 already ran this layer's q/k/v projection
     for (int l = lb; l < le; ++l) {
         const LayerWeights& lw = e->layers[l];
         elem_t* kpool = e->kv_pool + (size_t)l * e->kv_layer_elems;
         elem_t* vpool = kpool + e->kv_half_elems;
-        if (!qkv_done) {   // input RMSNorm -> q/k/v projections -> RoPE -> KV append
+        {   // input RMSNorm -> q/k/v projections -> RoPE -> KV append
             GemmParams p{};
             p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden;
             p.N = qdim + 2 * kvdim; p.n_tiles = p.N / 16;
@@ -756,18 +617,8 @@ static int run_layers(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int 
             LSK_TRY(profile_pair(e, LSK_PROF_QKV, m, (double)p.wp_bytes, &ea, &eb));
             LSK_TRY((launch_gemm<PRO_RMS, EPI_QKV>(p, e->target_wgs, st, nullptr, ea, eb)));
         }
-        if (e->fused_oproj && e->fused_attn && m <= 8 && e->heads_epoch < (1 << 24)) {
-            LSK_TRY(launch_attn_oproj(e, kpool, vpool, lw, x, m, pos_off, st));
-            qkv_done = false;
-        } else {
-            LSK_TRY(launch_attn(e, e->qbuf, e->attn, kpool, vpool, m, pos_off, st));
-            qkv_done = false;
-            if (e->chain && !e->profile) {
-                bool chained = false;
-                LSK_TRY(launch_chain(e, l, l + 1 < le, x, m, base_ptr, pos_off, st, &chained));
-                if (chained) { qkv_done = (l + 1 < le); continue; }
-            }
-            // o_proj + residual
+        LSK_TRY(launch_attn(e, e->qbuf, e->attn, kpool, vpool, m, pos_off, st));
+        {   // o_proj + residual
             GemmParams p{};
             p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
             p.wp = lw.wo; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
@@ -1350,9 +1201,7 @@ extern "C" int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t valu
         case LSK_OPT_BIG_THRESHOLD: e->big_threshold = value; return 0;
         case LSK_OPT_TARGET_WGS: e->target_wgs = value > 0 ? value : 256; return 0;
         case LSK_OPT_FUSED_ATTN: e->fused_attn = value != 0; return 0;
-        case LSK_OPT_FUSED_OPROJ: e->fused_oproj = value != 0; return 0;
         case LSK_OPT_FLASH_PREFILL: e->flash_prefill = value != 0; return 0;
-        case LSK_OPT_CHAIN: e->chain = value != 0; return 0;
         default: return lsk_fail("unknown option %d", option);
     }
 }
@@ -1637,8 +1486,12 @@ extern "C" int lsk_test_attention(const void* q, int32_t rows, int32_t n_heads, 
     sp.q = (const elem_t*)q; sp.ldq = qdim; sp.kpool = (const elem_t*)kpool; sp.vpool = (const elem_t*)vpool; sp.block_table = block_table_dev;
     sp.n_kv = n_kv_heads; sp.group = n_heads / n_kv_heads; sp.M = rows; sp.kv_len = kv_len_dev; sp.pos_off = pos_off;
     sp.scale_log2e = scale; sp.part = part; sp.max_pages = max_pages;
-    sp.counters = mode == 0 ? counters : nullptr; sp.out = (elem_t*)out; sp.ldo = qdim; sp.n_pages = pages; sp.heads_done = nullptr;
-    const dim3 grid(n_heads, pages), block(LSK_ATTN_THREADS);
+    sp.counters = mode == 0 ? counters : nullptr; sp.out = (elem_t*)out; sp.ldo = qdim; sp.n_pages = pages;
+    int hw = 1;
+    while (hw * 2 <= sp.group && hw * 2 * rows <= LSK_MAX_ROWS && sp.group % (hw * 2) == 0) hw *= 2;
+    sp.heads_per_wg = hw;
+    sp.inv_m = (256 + rows - 1) / rows;
+    const dim3 grid(n_heads / hw, pages), block(LSK_ATTN_THREADS);
     if (head_dim == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, sp);
     else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, sp);
     HIP_OK(hipGetLastError());

@@ -1,26 +1,31 @@
 // Decode / verify attention over the paged KV pool, split over KV pages ("flash-decoding" shape),
-// QK^T and PV on bf16 MFMA.
+// QK^T and PV on bf16 MFMA; the query heads of a GQA group share the fetch of a KV page as far as the 16 rows of an
+// MFMA tile allow.
 //
-//   grid  = (n_heads, pages in reach)      block = 4 waves
-//   phase 1 (lsk_attn_split_kernel): one workgroup = one query head x ONE 128-token KV page, one wave
-//           = 32 consecutive keys.  A wave issues ALL of its loads up front -- K as MFMA B-fragments
-//           straight from the page ([kv_head][slot][d] rows, 64 B per key per k-step), V as B-fragments
-//           from the TRANSPOSED page ([kv_head][d][slot]: 8 consecutive keys of one feature are 16
-//           contiguous bytes), Q as A-fragments (rows = the M <= 16 query rows) -- so ~256 workgroups
-//           keep > 4 MiB of KV reads in flight: the kernel is latency/bandwidth bound, the math
-//           (8 + 8 MFMAs per wave) is free.  S = QK^T lands in the MFMA C layout; causal masking is
-//           index arithmetic (row r at position base + r sees keys <= its position; this replaces the
-//           additive masks of llama_model_utils.py:21-59); fp32 softmax statistics per row via 16-lane
-//           butterflies; P is rounded to bf16 (as HF's eager path and torch's CPU flash kernel both do
-//           before the second GEMM), transposed C->A layout through 1 KiB of LDS per wave, O = P V.
-//           The 4 waves are merged in a fixed order into ONE (max, sum, acc[d]) partial per
-//           (row, head, page).
+//   grid  = (n_heads / HW, pages in reach)      block = 4 waves
+//   phase 1 (lsk_attn_split_kernel): one workgroup = HW query heads of ONE KV head x ONE 128-token KV page, one wave
+//           = 32 consecutive keys.  HW = min(group, 16 / M): the 16 rows of the MFMA tiles are row i = (head i / M,
+//           verify row i % M), so a llama3-8B draft pass (M = 1) serves its 4 query heads from ONE fetch of the page, a
+//           verify pass (M = 7) two heads per fetch; llama2-7B (MHA) and 13-row llama2-70B verify passes are HW = 1
+//           (repeat_kv, modeling_llama.py:179-188, never materialises).  Walking ALL group x M rows of a KV head in one
+//           workgroup (two tiles at 8B) was measured and rejected: 8 x pages workgroups and a 28-row serial combine
+//           made the verify pass 17.8 us against 7.0 us for the draft pass (profiles/r02_attention_gqa.md).
+//           A wave issues ALL of its loads up front -- K as MFMA B-fragments straight from
+//           the page ([kv_head][slot][d] rows, 64 B per key per k-step), V as B-fragments from the TRANSPOSED
+//           page ([kv_head][d][slot]: 8 consecutive keys of one feature are 16 contiguous bytes), Q as A-fragments.
+//           S = QK^T lands in the MFMA C layout; causal masking is index arithmetic (a row at position base + r sees
+//           keys <= its position; this replaces the additive masks of llama_model_utils.py:21-59); fp32 softmax
+//           statistics per row via 16-lane DPP reductions; P is rounded to bf16 (as HF's eager path and torch's flash
+//           kernels both do before the second GEMM), transposed C->A layout through 1 KiB of LDS per wave, O = P V.
+//           The 4 waves are merged in a fixed order into ONE (max, sum, acc[d]) partial per (row, head, page).
 //   phase 2: the page partials of a (row, head) are merged in page order into the bf16 attention output
-//           -- by the LAST page-workgroup of the head to arrive, inside the same launch (write-through
+//           -- by the LAST page-workgroup of the head column to arrive, inside the same launch (write-through
 //           partial stores + one relaxed agent-scope ticket, sc1 loads in the reducer; default), or by
 //           lsk_attn_combine_kernel as a second launch (LSK_OPT_FUSED_ATTN = 0; bit-identical).
 // Every row of the MFMA tiles is computed independently and the key partition depends only on the
-// absolute key index, so a row's result never depends on M or on the other rows of the pass.
+// absolute key index, so a row's result never depends on M, on the other rows of the pass or on the group size.
+// Never-written slots of the last page may hold anything (the pool is caller-owned memory): masked scores are
+// selected away and the V elements behind the last visible key are zeroed, so NaN / Inf patterns there cannot leak.
 // Replaces: LlamaAttention's repeat_kv + eager/SDPA attention (modeling_llama.py:179-213, :264-277).
 #pragma once
 #include "lsk_common.h"
@@ -44,12 +49,12 @@ struct AttnSplitParams {
     float scale_log2e;      // head_dim^-0.5 * log2(e)
     float* part;            // [n_heads][max_pages][16][HD + 2]
     int max_pages;
-    int* counters;          // [n_heads] arrival tickets (self-resetting); nullptr = separate combine kernel
-    elem_t* out;            // [M][ldo] attention output (written by the last-arriving page of a head)
+    int* counters;          // [n_heads / heads_per_wg] arrival tickets (self-resetting); nullptr = separate combine kernel
+    elem_t* out;            // [M][ldo] attention output (written by the last-arriving page of a head column)
     int ldo;
-    int n_pages;            // page-workgroups per head in this launch
-    int* heads_done;        // optional: bumped once per head after its output rows are published (write-through),
-                            // lets the o_proj role of lsk_attn_oproj_kernel start inside the same launch
+    int n_pages;            // page-workgroups per head column in this launch
+    int heads_per_wg;       // HW: query heads (of one KV head) per workgroup, HW * M <= 16, HW divides group
+    int inv_m;              // ceil(256 / M): i / M == (i * inv_m) >> 8 for every row index i < 16
 };
 
 #define LSK_ATTN_LDS_PBUF 0
@@ -67,7 +72,7 @@ struct AttnCombineParams {
 };
 
 template <int HD>
-__device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const int head, const int page_l, unsigned char* lds) {
+__device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const int col, const int page_l, unsigned char* lds) {
     constexpr int KS = HD / 32;              // k-steps of QK^T
     constexpr int DT = HD / 16;              // output column tiles of PV
     constexpr int PSTRIDE = HD + 2;
@@ -79,27 +84,32 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kvh = head / p.group;
     const int c16 = lane & 15;
     const int g = lane >> 4;
-    const int base_pos = *p.kv_len + p.pos_off;
     const int M = p.M;
+    const int HW = p.heads_per_wg;           // query heads of ONE KV head served by this workgroup: HW * M <= 16 rows
+    const int head0 = col * HW;              // first query head
+    const int kvh = head0 / p.group;
+    const int n_rows = HW * M;               // MFMA row i = (head head0 + i / M, verify row i % M)
     const int key0 = page_l * LSK_ATTN_PAGE;
     const bool fused = p.counters != nullptr;
-    if (key0 > base_pos + M - 1 && !fused) return;     // page entirely in the future of every row
-
     // ---- every load of this wave up front ----
     const int page = p.block_table[page_l];
+    const int base_pos = *p.kv_len + p.pos_off;
+    const int qi = min(c16, n_rows - 1);
+    const int qh = (qi * p.inv_m) >> 8;
+    const elem_t* qp = p.q + (size_t)(qi - qh * M) * p.ldq + (size_t)(head0 + qh) * HD + g * 8;
+    elem8 kb[2][KS], vb[DT], qa[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qa[ks] = *(const elem8*)(qp + ks * 32);
+    if (key0 > base_pos + M - 1 && !fused) return;     // page entirely in the future of every row
     const size_t head_base = ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD;
     const elem_t* kp = p.kpool + head_base + (size_t)(w * 32 + c16) * HD + g * 8;
     const elem_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + w * 32 + g * 8;
-    const elem_t* qp = p.q + (size_t)min(c16, M - 1) * p.ldq + head * HD + g * 8;
-    elem8 kb[2][KS], vb[DT], qa[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         kb[0][ks] = *(const elem8*)(kp + ks * 32);
         kb[1][ks] = *(const elem8*)(kp + 16 * HD + ks * 32);
-        qa[ks] = *(const elem8*)(qp + ks * 32);
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
@@ -129,10 +139,11 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
     unsigned char* pw = pbuf + w * 16 * PB_STRIDE;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = g * 4 + r;
-        const int lim = base_pos + row;      // last visible key of this row
-        const bool ok0 = (row < M) && (keyA <= lim);
-        const bool ok1 = (row < M) && (keyA + 16 <= lim);
+        const int i = g * 4 + r;
+        const int ih = (i * p.inv_m) >> 8;
+        const int lim = base_pos + (i - ih * M);     // last visible key of this row
+        const bool ok0 = (i < n_rows) && (keyA <= lim);
+        const bool ok1 = (i < n_rows) && (keyA + 16 <= lim);
         const float a0 = ok0 ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
         const float a1 = ok1 ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
         float m = fmaxf(a0, a1);
@@ -143,8 +154,8 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
         l = row16_sum(l);
         mrow[r] = m;
         lrow[r] = l;
-        *(elem_t*)(pw + row * PB_STRIDE + c16 * 2) = f2e(p0);
-        *(elem_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2e(p1);
+        *(elem_t*)(pw + i * PB_STRIDE + c16 * 2) = f2e(p0);
+        *(elem_t*)(pw + i * PB_STRIDE + (16 + c16) * 2) = f2e(p1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -167,13 +178,13 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
         }
     }
     __syncthreads();
-    // ---- merge the 4 waves (fixed order) into the page partial ----
-    for (int e = tid; e < M * PSTRIDE; e += LSK_ATTN_THREADS) {
-        const int r = e / PSTRIDE;
-        const int d = e - r * PSTRIDE;
+    // ---- merge the 4 waves (fixed order) into the page partial of each (head, row) ----
+    for (int e = tid; e < n_rows * PSTRIDE; e += LSK_ATTN_THREADS) {
+        const int i = e / PSTRIDE;
+        const int d = e - i * PSTRIDE;
         float m = LSK_ATTN_NEG;
 #pragma unroll
-        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + r) * PSTRIDE + HD]);
+        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + i) * PSTRIDE + HD]);
         float v;
         if (d == HD) {
             v = m;
@@ -181,71 +192,71 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
             v = 0.f;
 #pragma unroll
             for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
-                const float* src = sm + (ww * 16 + r) * PSTRIDE;
+                const float* src = sm + (ww * 16 + i) * PSTRIDE;
                 v += src[d] * __builtin_amdgcn_exp2f(src[HD] - m);      // d == HD + 1: the running sum l
             }
         }
-        float* dstp = p.part + (((size_t)head * p.max_pages + page_l) * LSK_ROWS + r) * PSTRIDE + d;
+        const int ih = (i * p.inv_m) >> 8;
+        float* dstp = p.part + (((size_t)(head0 + ih) * p.max_pages + page_l) * LSK_ROWS + (i - ih * M)) * PSTRIDE + d;
         if (fused) __hip_atomic_store(dstp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
         else *dstp = v;
     }
     if (!fused) return;
-    // ---- in-launch combine by the LAST page-workgroup of this head to arrive -------------------------
-    // Publish = write-through (sc1) partial stores, drained by every storing wave, then ONE relaxed
-    // agent-scope ticket; the last arriver reads all partials with sc1 loads (they bypass its L1 and the
-    // data was written through to memory, so no fence is needed on either side) and combines them in page
-    // order -- placement- and arrival-order independent, bit-identical to the two-kernel form.
+    // ---- in-launch combine by the LAST page-workgroup of this head column to arrive -------------------------
+    // Publish = write-through (sc1) partial stores, drained by EVERY storing wave (s_waitcnt vmcnt(0) + barrier), then ONE
+    // relaxed agent-scope ticket; the last arriver reads all partials with sc1 loads (L1-bypassing) and combines them in
+    // page order -- placement- and arrival-order independent, bit-identical to the two-kernel form.  This is the
+    // "sc1 payload -> drained -> sc1 flag, sc1 loads on the consumer" hand-off of the gfx950 guide (MI355X_MICROARCH.md,
+    // inter-workgroup visibility: sc1 loads may replace the acquire when the producer stored sc1): it needs no L2
+    // write-back / L1 invalidate, which is what makes it cheaper than a release/acquire pair; it relies on gfx950's sc1
+    // semantics, not on the C++ memory model -- tests/test_gpu_kernels.py keeps the bit-identity check against the
+    // two-kernel form (LSK_OPT_FUSED_ATTN = 0) as the gate for any toolchain change.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const int ticket = __hip_atomic_fetch_add(p.counters + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ticket = __hip_atomic_fetch_add(p.counters + col, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_last_p = (ticket == p.n_pages - 1);
     }
     __syncthreads();
     if (!*s_last_p) return;
-    const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
-    const bool publish = p.heads_done != nullptr;
-    for (int e = tid; e < M * (HD / 2); e += LSK_ATTN_THREADS) {
-        const int r = e / (HD / 2);
-        const int d = (e - r * (HD / 2)) * 2;          // two adjacent features per thread: one 32-bit store
+    for (int e = tid; e < n_rows * (HD / 2); e += LSK_ATTN_THREADS) {
+        const int i = e / (HD / 2);
+        const int d = (e - i * (HD / 2)) * 2;          // two adjacent features per thread: one 32-bit store
+        const int ih = (i * p.inv_m) >> 8;
+        const int r = i - ih * M;
+        const int head = head0 + ih;
+        const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
         const int n_pages = (base_pos + r) / LSK_ATTN_PAGE + 1;
         float m = LSK_ATTN_NEG, l = 0.f, a0 = 0.f, a1 = 0.f;
         for (int p0 = 0; p0 < n_pages; p0 += 8) {
             float mo[8], lo[8], x0[8], x1[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int pg = min(p0 + i, n_pages - 1);
+            for (int k = 0; k < 8; ++k) {
+                const int pg = min(p0 + k, n_pages - 1);
                 const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
-                mo[i] = __hip_atomic_load(src + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lo[i] = __hip_atomic_load(src + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                x0[i] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                x1[i] = __hip_atomic_load(src + d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mo[k] = __hip_atomic_load(src + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo[k] = __hip_atomic_load(src + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x0[k] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x1[k] = __hip_atomic_load(src + d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (p0 + i < n_pages) {
-                    const float mn = fmaxf(m, mo[i]);
+            for (int k = 0; k < 8; ++k) {
+                if (p0 + k < n_pages) {
+                    const float mn = fmaxf(m, mo[k]);
                     const float fa = __builtin_amdgcn_exp2f(m - mn);
-                    const float fb = __builtin_amdgcn_exp2f(mo[i] - mn);
-                    l = l * fa + lo[i] * fb;
-                    a0 = a0 * fa + x0[i] * fb;
-                    a1 = a1 * fa + x1[i] * fb;
+                    const float fb = __builtin_amdgcn_exp2f(mo[k] - mn);
+                    l = l * fa + lo[k] * fb;
+                    a0 = a0 * fa + x0[k] * fb;
+                    a1 = a1 * fa + x1[k] * fb;
                     m = mn;
                 }
             }
         }
         const elem_t o0 = f2e(a0 / l), o1 = f2e(a1 / l);
         const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
-        unsigned* op = (unsigned*)(p.out + (size_t)r * p.ldo + head * HD + d);
-        if (publish) __hip_atomic_store(op, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
-        else *op = packed;
+        *(unsigned*)(p.out + (size_t)r * p.ldo + head * HD + d) = packed;
     }
-    if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (publish) __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store(p.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (publish) __hip_atomic_fetch_add(p.heads_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) __hip_atomic_store(p.counters + col, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int HD>

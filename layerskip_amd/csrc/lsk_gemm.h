@@ -63,7 +63,7 @@ __host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS
 // wave's (in-order) load queue: `lsk_load_chunk` pulls this thread's 16-byte slice of every row of a
 // K-chunk into registers (issued before / under the weight stream), `lsk_store_chunk` applies the
 // RMSNorm (if any) and writes the bf16 rows to LDS later, without touching global memory.
-template <int PRO, int MB, bool COHERENT = false>
+template <int PRO, int MB>
 __device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int steps_c, int tid, elem8 (&xr)[MB], elem8& nw) {
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
@@ -71,18 +71,7 @@ __device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int s
         if (PRO == PRO_RMS) nw = *(const elem8*)(p.norm_w + k0);
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
-            const elem_t* src = p.x + (size_t)min(i, p.M - 1) * p.ldx + k0;
-            if (COHERENT) {
-                // rows published by another workgroup of the SAME launch with write-through stores: read them
-                // with agent-scope (sc1) loads, which bypass this CU's possibly stale L1 lines
-                unsigned long long lo = __hip_atomic_load((const unsigned long long*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long hi = __hip_atomic_load((const unsigned long long*)src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-                u64x2 v = {lo, hi};
-                xr[i] = __builtin_bit_cast(elem8, v);
-            } else {
-                xr[i] = *(const elem8*)src;
-            }
+            xr[i] = *(const elem8*)(p.x + (size_t)min(i, p.M - 1) * p.ldx + k0);
         }
     }
 }
@@ -110,24 +99,8 @@ __device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned ch
     }
 }
 
-// One arrival of this workgroup on a phase counter: every wave drains its own (write-through) stores first.
-__device__ __forceinline__ void lsk_phase_arrive(int* ctr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// WAIT: the activation rows (and, for EPI_RESID, the residual rows) are produced by other workgroups of the SAME
-// launch (role pipelining in lsk_attn_oproj_kernel, phase chaining in lsk_chain_kernel): fill the weight ring first,
-// then wait until *wait_flag >= wait_target, then read them with agent-scope loads.
-// PUBLISH: the rows this projection writes (EPI_RESID: h, EPI_SWIGLU: act) are consumed by a later phase of the same
-// launch: write-through (agent-scope) stores, drained by every wave, then ONE arrival ticket per workgroup on
-// `signal_ctr`.
-// RESID_LATE: the residual rows of EPI_RESID are themselves produced in this launch (lsk_chain_kernel's down phase):
-// they are read after the wait, with agent-scope loads, instead of up front.
-template <int PRO, int EPI, int MB, bool WAIT, bool PUBLISH = false, bool RESID_LATE = false>
-__device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int block_id, unsigned char* smem,
-                                              const int* wait_flag, const int wait_target, int* signal_ctr = nullptr) {
+template <int PRO, int EPI, int MB>
+__device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int block_id, unsigned char* smem) {
     float* slab = (float*)(smem + LSK_LDS_SLAB);
     float* red = (float*)(smem + LSK_LDS_RED);
     unsigned char* xs = smem + LSK_LDS_X;
@@ -156,7 +129,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     float pre_b[4] = {0.f, 0.f, 0.f, 0.f};      // QKV: sin
     int pre_pg[4] = {0, 0, 0, 0};               // QKV: KV page of each row's position
     int base_pos = 0;
-    if (EPI == EPI_RESID && !RESID_LATE) {
+    if (EPI == EPI_RESID) {
         if (is_owner) {
             const int n = (tile0 + w) * 16 + c16;
 #pragma unroll
@@ -196,42 +169,13 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     float ss[MB];
     float sv[MB];                 // per-row 1/rms (PRO_RMS), wave-uniform
     u32x4 ring[LSK_SPW];
-    if (WAIT) {
-        // rows not produced yet: start the weight stream, then wait for the producers (bounded spin)
-#pragma unroll
-        for (int s = 0; s < LSK_SPW; ++s) {
-            const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
-            ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
-        }
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_target && spins < (1 << 22)) {
-                __builtin_amdgcn_s_sleep(8);
-                ++spins;
-            }
-        }
-        __syncthreads();
-        if (EPI == EPI_RESID && RESID_LATE && is_owner) {
-            // the residual rows were written by an earlier phase of this launch: agent-scope loads
-            const int n = (tile0 + w) * 16 + c16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = rg * 4 + i;
-                if (row < M && n < p.N) {
-                    const unsigned short bits = __hip_atomic_load((const unsigned short*)(p.h + (size_t)row * p.ldh + n),
-                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pre_a[i] = e2f(__builtin_bit_cast(elem_t, bits));
-                }
-            }
-        }
-    }
     if (PRO == PRO_RMS) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) ss[i] = 0.f;
         // RMSNorm statistics need whole rows: walk the K-chunks last-to-first so chunk 0 stays in xr
         for (int c = nchunks - 1; c >= 0; --c) {
             const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
-            lsk_load_chunk<PRO, MB, WAIT>(p, c, steps_c, tid, xr, nw);
+            lsk_load_chunk<PRO, MB>(p, c, steps_c, tid, xr, nw);
             if (tid * 8 < steps_c * 32) {
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
@@ -240,14 +184,12 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             }
         }
     } else {
-        lsk_load_chunk<PRO, MB, WAIT>(p, 0, cur.steps_c, tid, xr, nw);
+        lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
     }
-    if (!WAIT) {
 #pragma unroll
-        for (int s = 0; s < LSK_SPW; ++s) {
-            const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
-            ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
-        }
+    for (int s = 0; s < LSK_SPW; ++s) {
+        const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
+        ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
     }
     if (PRO == PRO_RMS) {
 #pragma unroll
@@ -270,7 +212,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             sv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_inv), i));
     }
     lsk_store_chunk<PRO, MB>(p, xs, xstride, sv, cur.steps_c, tid, xr, nw);
-    if (nchunks > 1) lsk_load_chunk<PRO, MB, WAIT>(p, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);   // prefetch chunk 1
+    if (nchunks > 1) lsk_load_chunk<PRO, MB>(p, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);   // prefetch chunk 1
     __syncthreads();
 
     const int arow = min(lane & 15, M - 1);
@@ -293,7 +235,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             // of this chunk were prefetched into xr one chunk ago, the next chunk's are requested now
             lsk_store_chunk<PRO, MB>(p, xs, xstride, sv, cur.steps_c, tid, xr, nw);
             if (cur.c + 1 < nchunks)
-                lsk_load_chunk<PRO, MB, WAIT>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
+                lsk_load_chunk<PRO, MB>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const elem8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
@@ -340,10 +282,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
                 if (row < M && n < p.N) {
-                    const elem_t r = f2e(pre_a[i] + rnd_e(own0[i]));                 // residual + Linear(...) in model dtype
-                    if (PUBLISH) __hip_atomic_store((unsigned short*)(p.h + (size_t)row * p.ldh + n), __builtin_bit_cast(unsigned short, r),
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
-                    else p.h[(size_t)row * p.ldh + n] = r;
+                    p.h[(size_t)row * p.ldh + n] = f2e(pre_a[i] + rnd_e(own0[i]));   // residual + Linear(...) in model dtype
                 }
             }
         }
@@ -357,10 +296,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                     const float g = rnd_e(own0[i]);                    // gate_proj(x)
                     const float uu = rnd_e(own1[i]);                   // up_proj(x)
                     const float s = rnd_e(g / (1.0f + expf(-g)));      // silu in fp32, one rounding
-                    const elem_t r = f2e(s * uu);
-                    if (PUBLISH) __hip_atomic_store((unsigned short*)(p.act + (size_t)row * p.ldact + n), __builtin_bit_cast(unsigned short, r),
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
-                    else p.act[(size_t)row * p.ldact + n] = r;
+                    p.act[(size_t)row * p.ldact + n] = f2e(s * uu);
                 }
             }
         }
@@ -441,11 +377,10 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             p.part_idx[block_id * 16 + tid] = idx;
         }
     }
-    if (PUBLISH) lsk_phase_arrive(signal_ctr);
 }
 
 template <int PRO, int EPI, int MB>
 __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    lsk_gemm_body<PRO, EPI, MB, false>(p, blockIdx.x, smem, nullptr, 0);
+    lsk_gemm_body<PRO, EPI, MB>(p, blockIdx.x, smem);
 }

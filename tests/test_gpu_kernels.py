@@ -174,39 +174,6 @@ def test_fused_attention_combine_equals_two_kernel_form(gpu_device):
     eng.close()
 
 
-@pytest.mark.parametrize("shape", ["tiny-gqa", "tiny-d64"])
-def test_role_pipelined_attention_oproj_is_bit_identical(gpu_device, shape):
-    """lsk_attn_oproj_kernel (attention producers + o_proj consumers in one grid, in-launch hand-off) vs
-    the two-launch form: identical hidden states for 1-row and 7-row passes, over many back-to-back
-    launches (monotonic heads_done epochs, self-resetting tickets) and a growing context."""
-    from layerskip_amd import _lib, synthetic
-    from layerskip_amd.engine import BUF_BULK, BUF_STEP, HipEngine
-    cfg = synthetic.make_config(shape)
-    model = synthetic.build_model(cfg, seed=6, exit_layer=2, late_damping=0.1).to(gpu_device)
-    eng = HipEngine(model, max_ctx=1024, max_prompt=400)
-    ids = synthetic.make_prompt(cfg.vocab_size, 330, 8)
-    outs = []
-    for fused in (0, 1):
-        eng.set_option(_lib.LSK_OPT_FUSED_OPROJ, fused)
-        eng.reset()
-        eng.embed_rows(ids[:300], BUF_BULK, 0)
-        eng.run_bulk(300, 0, eng.num_layers)
-        eng.set_kv_len(300)
-        rows = []
-        pos = 0
-        for step in range(6):                       # alternating 1-row and 7-row passes, context grows
-            m = 1 if step % 2 == 0 else 7
-            eng.embed_rows(ids[300 + pos:300 + pos + m], BUF_STEP, 0)
-            eng.run_layers(BUF_STEP, 0, m, pos, 0, eng.num_layers)
-            rows.append(eng.read_rows(BUF_STEP, 0, m).clone())
-            pos += m
-        outs.append(torch.cat(rows))
-    torch.cuda.synchronize()
-    assert torch.isfinite(outs[1].float()).all()
-    assert torch.equal(outs[0], outs[1])
-    eng.close()
-
-
 def test_paged_kv_block_table_indirection(gpu_device):
     """The KV pool is paged: a permuted logical->physical block table must give bit-identical results
     (prefill kernels, decode kernels and attention all go through the table)."""
