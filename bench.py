@@ -185,6 +185,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
 
     for i in range(args.warmup):
         one(1000 + i)
+    engine.host_stats()                       # clear
     _barrier(world)
     t0 = time.perf_counter()
     results, step_traces = [], []
@@ -193,6 +194,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         step_traces.append(list(getattr(strategy, "last_steps", [])))   # host bookkeeping only
     _barrier(world)
     elapsed = time.perf_counter() - t0
+    host = engine.host_stats()
     tokens = sum(len(r.predicted_tokens) for r in results)
     acc = [r.acceptance_rate for r in results if r.acceptance_rate is not None]
 
@@ -218,6 +220,11 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
                    "strategy": args.strategy, "parallelism": "replica per GPU" if world > 1 else "single GPU"},
         "model_build_s": round(build_s, 1),
     }
+    if host["steps"]:
+        out["host"] = {"enqueue_ms_per_step": round(1e3 * host["enqueue_s"] / host["steps"], 3),
+                       "host_occupancy": round(host["enqueue_s"] / max(host["wall_s"], 1e-9), 3),
+                       "note": "time the one host thread spends enqueueing a speculation step (all its launches) vs the wall time of "
+                               "the fused generate calls; the rest of the time it sleeps on the step event"}
     if not full or rank != 0:
         del engine, model
         return out

@@ -302,6 +302,9 @@ int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t iters, floa
 /* Profiling of the dominant kernel: while enabled, every gate/up launch of the decode path is issued with its
  * own (start, stop) HIP events bound to the dispatch's begin / end timestamps (hipExtLaunchKernelGGL) on the
  * launch stream; lsk_engine_get_profile returns the summed duration and the launch count and clears the log. */
+/* Host-side cost of lsk_spec_generate / lsk_spec_generate_sampled since the last query: seconds the calling thread spent
+ * enqueueing steps, the calls' wall time, steps enqueued.  Clears the counters. */
+int lsk_engine_get_host_stats(lsk_engine* e, double* enqueue_s, double* wall_s, int64_t* steps);
 int lsk_engine_set_profile(lsk_engine* e, int32_t enable);
 int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* launches);
 /* The same for EVERY kernel class of the decode path: q/k/v (0), attention (1), o_proj (2), gate/up (3), down (4),

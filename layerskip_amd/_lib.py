@@ -102,6 +102,7 @@ PROTOTYPES = {
     "lsk_test_attention": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                      c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int32, c_void_p]),
     "lsk_time_gateup": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p]),
+    "lsk_engine_get_host_stats": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_int64)]),
     "lsk_engine_set_profile": (c_int32, [c_void_p, c_int32]),
     "lsk_engine_get_profile": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32)]),
     "lsk_engine_get_profile_table": (c_int32, [c_void_p, c_int32, POINTER(c_float), POINTER(c_int32), POINTER(ctypes.c_double)]),

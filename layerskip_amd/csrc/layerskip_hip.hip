@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -227,6 +228,9 @@ struct lsk_engine {
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    // host-side cost of the fused generate calls: time this thread spent enqueueing steps vs the wall time of the call
+    double host_enqueue_s = 0.0, host_wall_s = 0.0;
+    long long host_steps = 0;
     struct ProfRec { unsigned char cat; unsigned char multi; double bytes; };
     std::vector<ProfRec> prof_log;   // one record per event pair, in pool order
 };
@@ -933,6 +937,17 @@ static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t 
     LSK_TRY(lsk_engine_reset(e, stream));
     LSK_TRY(upload_step_inputs(e, prompt_ids, prompt_len, eos_token_ids, n_eos, st));
     int produced = 0, matches = 0, drafts = 0, steps = 0;
+    typedef std::chrono::steady_clock clk;
+    const clk::time_point t_call = clk::now();
+    double enq_s = 0.0;
+    long long enq_n = 0;
+#define LSK_TIMED_ENQUEUE(call)                                                            \
+    do {                                                                                   \
+        const clk::time_point _t0 = clk::now();                                            \
+        LSK_TRY(call);                                                                     \
+        enq_s += std::chrono::duration<double>(clk::now() - _t0).count();                  \
+        ++enq_n;                                                                           \
+    } while (0)
     StepSampling sm_step;
     uint64_t enq = 0;                        // steps enqueued so far: each one draws from its own Philox offset
     auto next_sm = [&]() -> const StepSampling* {
@@ -945,7 +960,7 @@ static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t 
     int pend_P = prompt_len, pend_S = S < max_steps - 1 ? S : max_steps - 1, slot = 0;
     if (pend_S < 0) pend_S = 0;
     e->kv_len_host = 0;
-    LSK_TRY(enqueue_step(e, pend_P, pend_S, exit_layer, n_eos, slot, st, next_sm()));
+    LSK_TIMED_ENQUEUE(enqueue_step(e, pend_P, pend_S, exit_layer, n_eos, slot, st, next_sm()));
     bool done = false;
     while (!done) {
         // the pending step emits between 1 and pend_S + 1 tokens; can the next one be decided already?
@@ -954,7 +969,7 @@ static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t 
         int next_slot = slot ^ 1;
         if (early) {
             e->kv_len_host = kv_true + pend_P + pend_S;          // upper bound of the context after the pending step
-            LSK_TRY(enqueue_step(e, 1, S, exit_layer, n_eos, next_slot, st, next_sm()));
+            LSK_TIMED_ENQUEUE(enqueue_step(e, 1, S, exit_layer, n_eos, next_slot, st, next_sm()));
         }
         HIP_OK(hipEventSynchronize(e->step_done[slot]));
         const int* r = e->host_result + slot * 64;
@@ -979,7 +994,7 @@ static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t 
         if (!early) {
             const int s_next = S < max_steps - produced - 1 ? S : max_steps - produced - 1;
             e->kv_len_host = kv_true;
-            LSK_TRY(enqueue_step(e, 1, s_next < 0 ? 0 : s_next, exit_layer, n_eos, next_slot, st, next_sm()));
+            LSK_TIMED_ENQUEUE(enqueue_step(e, 1, s_next < 0 ? 0 : s_next, exit_layer, n_eos, next_slot, st, next_sm()));
             pend_S = s_next < 0 ? 0 : s_next;
         } else {
             pend_S = S;
@@ -991,6 +1006,10 @@ static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t 
     // leave the engine consistent with the device: the verified length (a drained redundant step may have moved it)
     LSK_TRY(set_kv_len(e, kv_true, false, st));
     e->next_token_host = -1;
+#undef LSK_TIMED_ENQUEUE
+    e->host_enqueue_s += enq_s;
+    e->host_wall_s += std::chrono::duration<double>(clk::now() - t_call).count();
+    e->host_steps += enq_n;
     *n_out = produced;
     *total_matches = matches;
     *total_drafts = drafts;
@@ -1104,7 +1123,7 @@ extern "C" int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t 
     const int P = prompt_len, E = exit_layer;
     if (E < 1 || E > c.num_layers) return lsk_fail("exit_layer %d out of range 1..%d", E, c.num_layers);
     LSK_TRY(layers_bound(e, 0, E));
-    if (row0 < 0 || n_rows < 1 || row0 + n_rows + (head_last ? 1 : 0) > LSK_MAX_ROWS + (head_last ? 1 : 0) || row0 + n_rows > LSK_MAX_ROWS)
+    if (row0 < 0 || n_rows < 1 || row0 + n_rows > LSK_MAX_ROWS)
         return lsk_fail("lsk_draft_block: rows [%d,%d) exceed the %d-row step buffer", row0, row0 + n_rows, LSK_MAX_ROWS);
     if (head_last && row0 + n_rows >= LSK_MAX_ROWS) return lsk_fail("lsk_draft_block: no row left for the last head's token");
     if (pos_off0 < 0 || e->kv_len_host + pos_off0 + n_rows > c.max_ctx) return lsk_fail("lsk_draft_block: positions exceed max_ctx");
@@ -1533,6 +1552,16 @@ extern "C" int lsk_time_gateup(lsk_engine* e, int32_t layer, int32_t m, int32_t 
     if (rc != 0) return rc;
     if (err != hipSuccess) return lsk_fail("lsk_time_gateup: %s", hipGetErrorString(err));
     *ms_per_launch = ms / iters;
+    return 0;
+}
+
+// Host-side cost of the fused generate calls since the last query: seconds this thread spent ENQUEUEING speculation steps
+// (kernel launches, the result copy, the event), the calls' wall time, and the number of steps enqueued.  The ratio is the
+// host occupancy of a replica: what decides whether several engines per host need hipGraph replay.  Clears.
+extern "C" int lsk_engine_get_host_stats(lsk_engine* e, double* enqueue_s, double* wall_s, int64_t* steps) {
+    if (!e || !enqueue_s || !wall_s || !steps) return lsk_fail("null pointer");
+    *enqueue_s = e->host_enqueue_s; *wall_s = e->host_wall_s; *steps = e->host_steps;
+    e->host_enqueue_s = 0.0; e->host_wall_s = 0.0; e->host_steps = 0;
     return 0;
 }
 

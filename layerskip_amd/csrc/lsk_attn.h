@@ -234,10 +234,14 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
             for (int k = 0; k < 8; ++k) {
                 const int pg = min(p0 + k, n_pages - 1);
                 const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
-                mo[k] = __hip_atomic_load(src + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lo[k] = __hip_atomic_load(src + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                x0[k] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                x1[k] = __hip_atomic_load(src + d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (max, sum) and the two features are 8-byte aligned pairs (row stride (HD + 2) * 4 B, d even): one
+                // 64-bit sc1 load each instead of two 32-bit ones
+                const unsigned long long ml = __hip_atomic_load((const unsigned long long*)(src + HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long xx = __hip_atomic_load((const unsigned long long*)(src + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mo[k] = __builtin_bit_cast(float, (unsigned)ml);
+                lo[k] = __builtin_bit_cast(float, (unsigned)(ml >> 32));
+                x0[k] = __builtin_bit_cast(float, (unsigned)xx);
+                x1[k] = __builtin_bit_cast(float, (unsigned)(xx >> 32));
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

@@ -496,6 +496,12 @@ class HipEngine:
         self._ck(self.lib.lsk_engine_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    def host_stats(self) -> dict:
+        """Host cost of the fused generate calls since the last query (lsk_engine_get_host_stats)."""
+        a, b, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+        self._ck(self.lib.lsk_engine_get_host_stats(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
+        return {"enqueue_s": a.value, "wall_s": b.value, "steps": n.value}
+
     PROFILE_CLASSES = ("qkv", "attention", "o_proj", "gate_up", "down", "lm_head")
 
     def get_profile_table(self):

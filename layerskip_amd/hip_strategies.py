@@ -170,7 +170,8 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                                 sample: Optional[bool] = False, temperature: Optional[float] = 0.7,
                                 top_k: Optional[int] = 50, top_p: Optional[float] = 0.95,
                                 logits_processors=None, stopping_criteria=None, streamer=None):
-        engine = get_engine(model, **self.engine_kwargs)
+        # the packed weights are checked against the live model at the START of a generation, not on every step
+        engine = get_engine(model, check_weights=past_key_values is None, **self.engine_kwargs)
         if past_key_values is None:
             sp = max(0, num_speculations)
             engine.ensure_capacity(len(input_ids_list) + sp + 2, input_ids.shape[1] + (sp if sp > _lib.LSK_MAX_SPEC else 0))

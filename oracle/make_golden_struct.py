@@ -66,6 +66,8 @@ CASES = {
     "slice1b": StructCase("slice-1B", seed=0, prompt_len=40, max_steps=32),
     # BASELINE.json's headline shape at FULL size: 32 layers, exit_layer 8, 6 speculations (CPU-generated weights)
     "full7b": StructCase("llama2-7B", seed=0, prompt_len=64, max_steps=48, fp32=False),
+    # BASELINE config #3 at FULL size: llama3-8B, GQA 32/8, V = 128 256, theta = 5e5, exit_layer 8, 6 speculations
+    "full8b": StructCase("llama3-8B", seed=0, prompt_len=64, max_steps=48, fp32=False),
     "tiny_gqa_eos": StructCase("tiny-gqa", seed=0, prompt_len=37, max_steps=48, eos_from="tiny_gqa", eos_index=9),
     "tiny_mha_eos": StructCase("tiny-mha", seed=2, prompt_len=24, max_steps=48, eos_from="tiny_mha", eos_index=5),
 }

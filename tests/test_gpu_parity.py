@@ -386,3 +386,29 @@ def test_engine_is_released_with_its_model(gpu_device):
     del eng, model
     gc.collect()
     assert ref() is None
+
+
+def test_engine_follows_weight_changes_on_the_same_model_object(gpu_device):
+    """The engine streams packed COPIES of the projections; the reference reads live weights.  After load_state_dict (or
+    any in-place edit) on the same model object the next generation must use the new weights: get_engine() compares the
+    (address, version) fingerprint taken at pack time and re-packs."""
+    from conftest import build_struct_model, load_struct
+    from layerskip_amd import GenerationConfig
+    from layerskip_amd.engine import get_engine
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    rec_a, rec_b = load_struct("tiny_gqa"), load_struct("tiny_gqa_spec15")        # same shape, different seeds
+    model = build_struct_model(rec_a, gpu_device)
+    other = build_struct_model(rec_b, gpu_device)
+    strat = HipSelfSpeculativeGenerationStrategy()
+    cfg = GenerationConfig(max_steps=rec_a["max_steps"], exit_layer=rec_a["exit_layer"], num_speculations=rec_a["num_speculations"], sample=False)
+    a = strat.generate_token_ids(model, rec_a["prompt"], rec_a["eos_token_ids"], cfg)
+    assert a.predicted_tokens == rec_a["bf16"]["spec_tokens"]
+    eng = get_engine(model)
+    assert not eng.weights_changed(model)
+    model.load_state_dict(other.state_dict())                 # in-place copy_ into the same Parameters: versions bump
+    assert eng.weights_changed(model)
+    cfg_b = GenerationConfig(max_steps=rec_b["max_steps"], exit_layer=rec_b["exit_layer"], num_speculations=rec_b["num_speculations"], sample=False)
+    b = strat.generate_token_ids(model, rec_b["prompt"], rec_b["eos_token_ids"], cfg_b)
+    assert get_engine(model) is eng and not eng.weights_changed(model)
+    assert b.predicted_tokens == rec_b["bf16"]["spec_tokens"]
+    assert b.acceptance_rate == rec_b["bf16"]["acceptance_rate"]

@@ -262,3 +262,33 @@ def test_cli_drivers_report_the_reference_metric_keys(patched, monkeypatch, caps
     assert exc.value.code == 0
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert out["errors"] == 0 and out["error_pct"] == 0 and out["num_samples"] == 2
+
+
+def test_sweep_driver_writes_the_reference_csv(patched, monkeypatch, tmp_path):
+    """sweep.py (reference sweep.py:47-65): one CSV row per (exit_layer, num_speculations) grid point with the reference's
+    column names, rewritten after every point."""
+    import csv
+    import importlib.util
+    import sys
+    from conftest import ROOT
+    w = patched
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        monkeypatch.setitem(sys.modules, name, mod)
+        spec.loader.exec_module(mod)
+        return mod
+
+    load("benchmark")
+    sweep = load("sweep")
+    monkeypatch.setattr(sweep, "load_model_and_tokenizer", lambda args, syn, exit_layer: (w["base"], None))
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    monkeypatch.setattr(sys, "argv", ["sweep.py", "--model", "synthetic:tiny-gqa", "--num_samples", "1", "--prompt_len", "10", "--device", "cpu",
+                                      "--max_steps", "6", "--exit_layer_first", "3", "--exit_layer_last", "3", "--num_speculations_first", "2",
+                                      "--num_speculations_last", "4", "--num_speculations_step", "2", "--output_dir", str(tmp_path)])
+    sweep.main()
+    rows = list(csv.DictReader(open(tmp_path / "sweep.csv")))
+    assert [(r["exit_layer"], r["num_speculations"]) for r in rows] == [("3", "2"), ("3", "4")]
+    assert set(rows[0]) == {"exit_layer", "num_speculations", "acceptance_rate", "time_per_token", "tokens_per_second"}
+    assert all(float(r["tokens_per_second"]) > 0 for r in rows)
