@@ -65,9 +65,9 @@ CASES = {
     "slice13b": StructCase("slice-13B", seed=0, prompt_len=40, max_steps=32, fp32=False),
     "slice1b": StructCase("slice-1B", seed=0, prompt_len=40, max_steps=32),
     # BASELINE.json's headline shape at FULL size: 32 layers, exit_layer 8, 6 speculations (CPU-generated weights)
-    "full7b": StructCase("llama2-7B", seed=0, prompt_len=64, max_steps=48, fp32=False),
+    "full7b": StructCase("llama2-7B", seed=0, prompt_len=64, max_steps=48),
     # BASELINE config #3 at FULL size: llama3-8B, GQA 32/8, V = 128 256, theta = 5e5, exit_layer 8, 6 speculations
-    "full8b": StructCase("llama3-8B", seed=0, prompt_len=64, max_steps=48, fp32=False),
+    "full8b": StructCase("llama3-8B", seed=0, prompt_len=64, max_steps=48),
     "tiny_gqa_eos": StructCase("tiny-gqa", seed=0, prompt_len=37, max_steps=48, eos_from="tiny_gqa", eos_index=9),
     "tiny_mha_eos": StructCase("tiny-mha", seed=2, prompt_len=24, max_steps=48, eos_from="tiny_mha", eos_index=5),
 }
@@ -126,8 +126,15 @@ def logits_rows(logits: torch.Tensor, rows, k=16, stride_n=16, exact: Optional[t
 
 
 def one_dtype(ref, model_bf16, case, prompt, eos, dtype, inplace: bool, exact=None):
-    """exact: (seq, full-depth fp32 logits, early-exit fp32 logits) of the reference's fp32 run, or None."""
-    model = model_bf16 if (inplace and dtype == torch.bfloat16) else copy.deepcopy(model_bf16).to(dtype)
+    """exact: (seq, full-depth fp32 logits, early-exit fp32 logits) of the reference's fp32 run, or None.
+    inplace (multi-GB checkpoints): the ONE model object is converted to `dtype` in place -- bf16 -> fp32 -> bf16 is exact,
+    the values are bf16-representable -- so the fp32 run of a 7-8B model needs 32 GB, not 16 + 32."""
+    if inplace:
+        model = model_bf16
+        for prm in model.parameters():
+            prm.data = prm.data.to(dtype)
+    else:
+        model = copy.deepcopy(model_bf16).to(dtype)
     ref_shim.patch_model(model)
     t0 = time.time()
     ref_spec = run_reference(ref, model, prompt, eos, case, "self_speculative")

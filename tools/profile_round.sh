@@ -9,13 +9,13 @@ export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-gpu-reference --no-sampled"
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o stats -- $BENCH --steps 2 --warmup 1 > "$OUT/stats_bench.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o stats -- $BENCH --steps 2 --warmup 1 > "$OUT/stats_bench.log" 2>&1
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_7B_spec.csv"
 SHORT="$BENCH --steps 1 --warmup 0 --max-steps 48"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
   tag=$(echo $pass | cut -d' ' -f1)
   rm -rf /tmp/prof_pmc
-  timeout 600 rocprofv3 --kernel-trace --pmc $pass -d /tmp/prof_pmc -o pmc -- $SHORT > "$OUT/pmc_$tag.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $pass -d /tmp/prof_pmc -o pmc -- $SHORT > "$OUT/pmc_$tag.log" 2>&1
   python $REPO/tools/pmc_summary.py /tmp/prof_pmc "$OUT/pmc_$tag.csv" >> "$OUT/pmc_$tag.log" 2>&1
 done
 ls -la "$OUT"
