@@ -116,11 +116,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        limit = datetime.timedelta(minutes=10)          # a lost rank must surface as an error, not as a hang
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=limit)
 
     E = args.exit_layer or synthetic.default_exit_layer(args.model)
     S = args.num_speculations or synthetic.default_num_speculations(args.model)

@@ -292,3 +292,26 @@ def test_sweep_driver_writes_the_reference_csv(patched, monkeypatch, tmp_path):
     assert [(r["exit_layer"], r["num_speculations"]) for r in rows] == [("3", "2"), ("3", "4")]
     assert set(rows[0]) == {"exit_layer", "num_speculations", "acceptance_rate", "time_per_token", "tokens_per_second"}
     assert all(float(r["tokens_per_second"]) > 0 for r in rows)
+
+
+def test_generate_repl_driver(patched, monkeypatch, capsys):
+    """generate.py (reference generate.py:95-161): the REPL decodes a prompt of token ids and prints the reference's footer."""
+    import builtins
+    import importlib.util
+    import sys
+    from conftest import ROOT
+    w = patched
+    spec = importlib.util.spec_from_file_location("lsk_generate_cli", os.path.join(ROOT, "generate.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "load_model_and_tokenizer", lambda args, syn, exit_layer: (w["base"], None))
+    ids = w["tok"].encode(PROMPT)
+    lines = iter([" ".join(str(i) for i in ids), "exit"])
+    monkeypatch.setattr(builtins, "input", lambda prompt="": next(lines))
+    monkeypatch.setattr(sys, "argv", ["generate.py", "--model", "synthetic:tiny-gqa", "--device", "cpu", "--max_steps", "8", "--exit_layer", "3",
+                                      "--num_speculations", "4", "--sample", "False", "--generation_strategy", "self_speculative"])
+    mod.main()
+    out = capsys.readouterr().out
+    assert "Tokens per second:" in out and "Acceptance rate:" in out and "Time per token:" in out
+    toks = [int(t) for t in out.split("[", 1)[1].split("]", 1)[0].split(",")]
+    assert len(toks) == 8
