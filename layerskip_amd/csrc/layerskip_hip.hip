@@ -679,9 +679,15 @@ static int embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, elem_t* d
     return 0;
 }
 
+#ifndef LSK_BIG_NTW_WIDE
+#define LSK_BIG_NTW_WIDE 2        // 16-column tiles per wave of the q/k/v and gate/up prefill launches (4: one wave per SIMD, 2x slower)
+#endif
+
 template <int EPI, int NTW>
 static int launch_big(BigGemmParams& p, hipStream_t st) {
-    const dim3 grid((p.M + LSK_BIG_BM - 1) / LSK_BIG_BM, (p.n_tiles + 4 * NTW - 1) / (4 * NTW));
+    const int rb = (p.M + LSK_BIG_BM - 1) / LSK_BIG_BM;                    // row blocks
+    const int panels = (p.n_tiles + 4 * NTW - 1) / (4 * NTW);              // weight panels of 4 * NTW tiles
+    const dim3 grid(rb * 8 * ((panels + 7) / 8));                          // XCD-aware 1-D map: lsk_gemm_big.h
     hipLaunchKernelGGL((lsk_gemm_big_kernel<EPI, NTW>), grid, dim3(LSK_BIG_THREADS), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
@@ -711,7 +717,7 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
             p.q_out = e->q_bulk; p.ldq = qdim; p.kpool = kpool; p.vpool = vpool; p.block_table = e->block_table; p.page_size = c.page_size;
             p.n_heads = c.n_heads; p.n_kv = c.n_kv_heads; p.head_dim = c.head_dim; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
             p.kv_len = kvp; p.pos_off = 0;
-            LSK_TRY((launch_big<EPI_QKV, 2>(p, st)));
+            LSK_TRY((launch_big<EPI_QKV, LSK_BIG_NTW_WIDE>(p, st)));
         }
         if (e->flash_prefill) {
             AttnPrefillParams ap{};
@@ -740,7 +746,7 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
             BigGemmParams p{};
             p.x = e->xn_bulk; p.ldx = c.hidden; p.M = n; p.K = c.hidden; p.wp = lw.wgu; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
             p.act = e->act_bulk; p.ldact = c.intermediate;
-            LSK_TRY((launch_big<EPI_SWIGLU, 2>(p, st)));
+            LSK_TRY((launch_big<EPI_SWIGLU, LSK_BIG_NTW_WIDE>(p, st)));
         }
         {
             BigGemmParams p{};
@@ -756,7 +762,8 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
 // MFMA-tiled prefill kernels for real prompts, 16-row passes of the decode kernels for short ones.
 static int run_bulk(lsk_engine* e, int n, const int* base_ptr, int lb, int le, hipStream_t st) {
     const lsk_config& c = e->cfg;
-    const bool big_ok = (c.hidden % LSK_BIG_BK == 0) && ((c.n_heads * c.head_dim) % LSK_BIG_BK == 0) && (c.intermediate % LSK_BIG_BK == 0);
+    const int kq = LSK_BIG_BK * LSK_BIG_PB;      // the prefill kernel walks K in runs of LSK_BIG_PB tiles
+    const bool big_ok = (c.hidden % kq == 0) && ((c.n_heads * c.head_dim) % kq == 0) && (c.intermediate % kq == 0);
     if (n >= e->big_threshold && big_ok) return run_bulk_big(e, n, lb, le, st);
     for (int r0 = 0; r0 < n; r0 += LSK_MAX_ROWS) {
         const int m = (n - r0) < LSK_MAX_ROWS ? (n - r0) : LSK_MAX_ROWS;

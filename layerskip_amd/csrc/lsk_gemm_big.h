@@ -6,8 +6,8 @@
 // workgroup, A tile (activations) staged through a double-buffered, padded LDS image, B fragments
 // (weights) straight from the packed tiles to VGPRs (each wave owns two adjacent 16-column tiles, i.e.
 // exactly one gate/up pair or one RoPE tile pair), register-prefetch of the next K-tile under the
-// current MFMAs, one barrier per K-tile.  blockIdx.x walks the row blocks so the workgroups that share
-// a weight panel are dispatched together (panel re-reads hit L2 / Infinity Cache, not HBM).
+// current MFMAs, one barrier per K-tile.  The block id is mapped XCD-aware (see the kernel): the row blocks that
+// share a weight panel run on ONE XCD, so the panel is fetched from HBM once and re-read from that XCD's L2.
 // Epilogues are the ones of lsk_gemm.h (bf16 rounding points of the HF modules).
 // Only prompt rows that are NOT decision rows go through here (their logits are never used), so the
 // different accumulation order never reaches an argmax; it only fills KV pages / exit hiddens.
@@ -17,6 +17,12 @@
 #define LSK_BIG_BM 128
 #define LSK_BIG_BK 64
 #define LSK_BIG_THREADS 256
+#ifndef LSK_BIG_PB
+#define LSK_BIG_PB 2             // K-tiles of weight fragments in flight per wave (even; 4 and 6 measured no faster)
+#endif
+#ifndef LSK_BIG_ALINE
+#define LSK_BIG_ALINE 1          // activation staging loads whole 128-byte lines (8 lanes per row) instead of 64 bytes per thread
+#endif
 #define LSK_BIG_LDA 160          // bytes per LDS row: 64 bf16 + 32 B pad (slot (10r + g) mod 16: conflict-free A-fragment reads)
 
 struct BigGemmParams {
@@ -49,7 +55,7 @@ struct BigGemmParams {
     int pos_off;
 };
 
-// NTW = packed 16-column tiles per wave: 2 (128-column workgroup tile; needed by the SwiGLU / RoPE pairs) or
+// NTW = packed 16-column tiles per wave: 4 or 2 (256- / 128-column workgroup tile; SwiGLU needs the gate/up PAIRS in one wave) or
 // 1 (64-column tile: twice the workgroups for the N = hidden projections, which otherwise fill half the chip).
 template <int EPI, int NTW>
 __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const BigGemmParams p) {
@@ -57,76 +63,122 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * LSK_BIG_BM;
-    const int T0 = (blockIdx.y * 4 + w) * NTW;           // this wave's first packed tile
+    // XCD-aware block -> (row block, weight panel) map.  Workgroup b runs on XCD b % 8, each XCD has its own L2, and the RB row
+    // blocks of one weight panel read the SAME weights: in a (row block, panel) grid they land on RB different XCDs and the panel
+    // is fetched from HBM RB times (measured: 730 MB per gate/up launch for 180 MB of weights, r02_pmc_hbm_traffic.csv).  Here
+    // every run of RB x 8 consecutive ids holds 8 panels, panel = run * 8 + (id % 8), row block = (id % (RB*8)) / 8: the RB
+    // workgroups of a panel share id % 8, i.e. one XCD and one L2 fetch, and are dispatched within one run of each other.
+    const int RB = (p.M + LSK_BIG_BM - 1) / LSK_BIG_BM;
+    const int run = blockIdx.x / (RB * 8);
+    const int idx = blockIdx.x - run * (RB * 8);
+    const int panel = run * 8 + (idx & 7);
+    const int m0 = (idx >> 3) * LSK_BIG_BM;
+    const int T0 = (panel * 4 + w) * NTW;               // this wave's first packed tile
+    if (panel * 4 * NTW >= p.n_tiles) return;           // padding of the last run
     const int ksteps = p.K >> 5;
     const int nkt = p.K / LSK_BIG_BK;
     const bool tile_ok = T0 < p.n_tiles;
-    const bool tile1_ok = (NTW == 2) && (T0 + 1 < p.n_tiles);
 
+#if LSK_BIG_ALINE
+    // A staging: a K-tile row is ONE 128-byte line (64 bf16).  Eight lanes fetch a row's line with one 16-byte load each, a wave
+    // instruction covers 8 whole lines (the texture addresser walks lines, not bytes: 64 bytes per thread over 32 rows cost 4x the
+    // address cycles for the same data); piece i of a thread is row (tid >> 3) + 32 i, 16-byte column tid & 7.
+    const int arow = tid >> 3;
+    const int acol = tid & 7;
+    const elem_t* aptr_i[4];
+    unsigned char* awr_i[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = arow + 32 * i;
+        aptr_i[i] = p.x + (size_t)min(m0 + r, p.M - 1) * p.ldx + acol * 8;
+        awr_i[i] = lds + r * LSK_BIG_LDA + acol * 16;
+    }
+#else
     // A staging: thread -> (row, 64-byte half)
     const int arow = tid >> 1;
     const int ahalf = tid & 1;
     const int grow = min(m0 + arow, p.M - 1);
     const elem_t* aptr = p.x + (size_t)grow * p.ldx + ahalf * 32;
     unsigned char* awr = lds + arow * LSK_BIG_LDA + ahalf * 64;
-    // B fragments: packed tile T, k-step s at ((T*ksteps + s)*64 + lane)*8 elements
-    const elem_t* bptr0 = p.wp + ((size_t)T0 * ksteps * 64 + lane) * 8;
-    const elem_t* bptr1 = bptr0 + (size_t)ksteps * 512;
+#endif
+    // B fragments: packed tile T, k-step s at ((T*ksteps + s)*64 + lane)*8 elements.  A wave whose tile lies beyond the matrix
+    // (last panel of a ragged N) streams the last valid tile instead and drops the result: every load of the K loop is
+    // UNCONDITIONAL -- a "tile ok ? load : zero" select makes hipcc branch around each load and fall back to s_waitcnt vmcnt(0)
+    // in front of the MFMAs (measured in the ISA: the prefetched tiles were drained every iteration).
+    const elem_t* bptr[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) bptr[nt] = p.wp + ((size_t)min(T0 + nt, p.n_tiles - 1) * ksteps * 64 + lane) * 8;
 
-    f32x4 acc[8][2];
+    f32x4 acc[8][NTW];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    elem8 areg[4];
-    elem8 bcur[2][2], bnxt[2][2];
-    const elem8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Weight fragments: a register ring LSK_BIG_PB K-tiles deep per wave, refilled the moment a slot is consumed.  Activations:
+    // two register sets (tiles kt+1, kt+2) feeding the double-buffered LDS image.  Slot indices are static: the K loop is
+    // unrolled by the ring depth, every load is unconditional, so every s_waitcnt in the loop is a COUNTED one.
+    elem8 aq[2][4];
+    elem8 bq[LSK_BIG_PB][NTW][2];
+    auto load_a = [&](int kt, elem8 (&dst)[4]) {
+#if LSK_BIG_ALINE
 #pragma unroll
-    for (int i = 0; i < 4; ++i) areg[i] = *(const elem8*)(aptr + i * 8);
+        for (int i = 0; i < 4; ++i) dst[i] = *(const elem8*)(aptr_i[i] + (size_t)kt * LSK_BIG_BK);
+#else
+        const elem_t* an = aptr + (size_t)kt * LSK_BIG_BK;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bcur[0][s] = tile_ok ? *(const elem8*)(bptr0 + (size_t)s * 512) : zero8;
-        bcur[1][s] = tile1_ok ? *(const elem8*)(bptr1 + (size_t)s * 512) : zero8;
-    }
+        for (int i = 0; i < 4; ++i) dst[i] = *(const elem8*)(an + i * 8);
+#endif
+    };
+    auto store_a = [&](int buf, const elem8 (&src)[4]) {
+#if LSK_BIG_ALINE
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(elem8*)(awr + i * 16) = areg[i];
+        for (int i = 0; i < 4; ++i) *(elem8*)(awr_i[i] + buf * (LSK_BIG_BM * LSK_BIG_LDA)) = src[i];
+#else
+        unsigned char* dst = awr + buf * (LSK_BIG_BM * LSK_BIG_LDA);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(elem8*)(dst + i * 16) = src[i];
+#endif
+    };
+    auto load_b = [&](int kt, elem8 (&dst)[NTW][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const size_t bo = (size_t)(kt * 2 + s) * 512;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) dst[nt][s] = *(const elem8*)(bptr[nt] + bo);
+        }
+    };
+    // nkt is a multiple of LSK_BIG_PB (the host takes the 16-row path otherwise); indices past the end are clamped to the last
+    // tile (a few redundant loads at the tail) so that the loop body has no data-dependent branch and every wait is counted
+    const int last = nkt - 1;
+    load_a(0, aq[0]);
+    load_a(min(1, last), aq[1]);
+#pragma unroll
+    for (int u = 0; u < LSK_BIG_PB; ++u) load_b(min(u, last), bq[u]);
+    store_a(0, aq[0]);
     __syncthreads();
 
     const unsigned char* ard = lds + (lane & 15) * LSK_BIG_LDA + (lane >> 4) * 16;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            const elem_t* an = aptr + (size_t)(kt + 1) * LSK_BIG_BK;
+    for (int kt0 = 0; kt0 < nkt; kt0 += LSK_BIG_PB) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) areg[i] = *(const elem8*)(an + i * 8);
+        for (int u = 0; u < LSK_BIG_PB; ++u) {
+            const int kt = kt0 + u;
+            const int cur = u & 1;                            // LSK_BIG_PB is even: kt & 1 == u & 1
+            load_a(min(kt + 2, last), aq[cur]);               // aq[cur] held tile kt: already in LDS
+            const unsigned char* abase = ard + cur * (LSK_BIG_BM * LSK_BIG_LDA);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const size_t bo = (size_t)((kt + 1) * 2 + s) * 512;
-                bnxt[0][s] = tile_ok ? *(const elem8*)(bptr0 + bo) : zero8;
-                bnxt[1][s] = tile1_ok ? *(const elem8*)(bptr1 + bo) : zero8;
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const elem8 a = *(const elem8*)(abase + mt * 16 * LSK_BIG_LDA + s * 64);
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = LSK_MFMA_16x16x32(a, bq[u][nt][s], acc[mt][nt], 0, 0, 0);
+                }
             }
+            load_b(min(kt + LSK_BIG_PB, last), bq[u]);        // refill the slot just consumed
+            store_a(cur ^ 1, aq[cur ^ 1]);                    // tile kt + 1 (loaded one iteration ago) -> the other LDS buffer
+            __syncthreads();
         }
-        const unsigned char* abase = ard + cur * (LSK_BIG_BM * LSK_BIG_LDA);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                const elem8 a = *(const elem8*)(abase + mt * 16 * LSK_BIG_LDA + s * 64);
-                acc[mt][0] = LSK_MFMA_16x16x32(a, bcur[0][s], acc[mt][0], 0, 0, 0);
-                if (NTW == 2) acc[mt][1] = LSK_MFMA_16x16x32(a, bcur[1][s], acc[mt][1], 0, 0, 0);
-            }
-        }
-        if (more) {
-            unsigned char* dst = awr + (cur ^ 1) * (LSK_BIG_BM * LSK_BIG_LDA);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *(elem8*)(dst + i * 16) = areg[i];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) { bcur[0][s] = bnxt[0][s]; bcur[1][s] = bnxt[1][s]; }
-        }
-        __syncthreads();
     }
     if (!tile_ok) return;
 
@@ -148,19 +200,22 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
                 }
         }
     } else if (EPI == EPI_SWIGLU) {
-        const int n = (T0 >> 1) * 16 + c16;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int pr = 0; pr < NTW / 2; ++pr) {               // gate / up tiles are interleaved pairwise
+            const int n = ((T0 >> 1) + pr) * 16 + c16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m0 + mt * 16 + rg * 4 + i;
-                if (row < p.M && n < (p.N >> 1)) {
-                    const float g = rnd_e(acc[mt][0][i]);
-                    const float uu = rnd_e(acc[mt][1][i]);
-                    const float s = rnd_e(g / (1.0f + expf(-g)));
-                    p.act[(size_t)row * p.ldact + n] = f2e(s * uu);
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + mt * 16 + rg * 4 + i;
+                    if (row < p.M && n < (p.N >> 1)) {
+                        const float g = rnd_e(acc[mt][2 * pr][i]);
+                        const float uu = rnd_e(acc[mt][2 * pr + 1][i]);
+                        const float s = rnd_e(g / (1.0f + expf(-g)));
+                        p.act[(size_t)row * p.ldact + n] = f2e(s * uu);
+                    }
                 }
-            }
+        }
     } else if (EPI == EPI_QKV) {
         const int hd = p.head_dim;
         const int tph = hd >> 4;
@@ -168,7 +223,7 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
         const int nk_t = p.n_kv * tph;
         const int base_pos = *p.kv_len + p.pos_off;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             const int T = T0 + nt;
             if (T >= p.n_tiles) continue;
             const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);

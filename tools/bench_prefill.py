@@ -1,22 +1,29 @@
-"""GPU micro-benchmark (not a test): prompt prefill time, flash-shaped vs chunked attention."""
+"""GPU micro-benchmark (not a test): prompt prefill time (all layers) of the llama2-7B shape.
+
+    python tools/bench_prefill.py [rows ...]          # default 511 2047; FLASH=0 also times the chunked-attention path
+"""
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from layerskip_amd import _lib, synthetic  # noqa: E402
 from layerskip_amd.engine import BUF_BULK, HipEngine  # noqa: E402
 
-cfg = synthetic.make_config("llama2-7B")
+if os.environ.get("LSK_LIB"):          # a variant build of the extension (kernel experiments)
+    _lib._LIBS["bf16"] = _lib.load(os.environ["LSK_LIB"])
+rows = [int(a) for a in sys.argv[1:]] or [511, 2047]
+cfg = synthetic.make_config(os.environ.get("MODEL", "llama2-7B"))
 model = synthetic.build_model(cfg, seed=0, exit_layer=8, late_damping=0.03, device="cuda:0", gen_device="cuda:0")
-for n in (511, 2047):
+for n in rows:
     eng = HipEngine(model, max_ctx=n + 129, max_prompt=n + 1)
     ids = synthetic.make_prompt(cfg.vocab_size, n, 1)
-    for flash in (0, 1):
+    for flash in ((0, 1) if os.environ.get("FLASH") == "0" else (1,)):
         eng.set_option(_lib.LSK_OPT_FLASH_PREFILL, flash)
         ts = []
-        for it in range(3):
+        for it in range(4):
             eng.reset()
             eng.embed_rows(ids, BUF_BULK, 0)
             torch.cuda.synchronize()
