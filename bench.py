@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--gpu-reference", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling: now the default
     ap.add_argument("--gpu-reference-tokens", type=int, default=128)
     ap.add_argument("--no-sampled", action="store_true", help="skip the sample=True throughput leg")
+    ap.add_argument("--graph-steps", action="store_true",
+                    help="replay steady-state speculation steps from hipGraphs (LSK_OPT_GRAPH_STEPS; default off, DESIGN.md 3.3)")
     return ap.parse_args()
 
 
@@ -174,6 +176,9 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
     if big:
         args.no_cpu_baseline = args.no_gpu_reference = True
         torch.cuda.empty_cache()
+    if args.graph_steps:
+        from layerskip_amd import _lib
+        engine.set_option(_lib.LSK_OPT_GRAPH_STEPS, 1)
     spec = args.strategy == "self_speculative"
     strategy = HipSelfSpeculativeGenerationStrategy() if spec else HipAutoRegressiveGenerationStrategy()
     gen = GenerationConfig(max_steps=args.max_steps, exit_layer=E if spec else -1, num_speculations=S if spec else -1,
@@ -219,7 +224,8 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         "acceptance_rate": round(sum(acc) / len(acc), 4) if acc else None,
         "config": {"workload": f"{args.model} shape, exit_layer={E}, num_speculations={S}, {args.prompt_len}-token prompt, "
                                f"{args.max_steps} new tokens, batch 1, greedy, random-init weights (late damping {args.late_damping})",
-                   "strategy": args.strategy, "parallelism": "replica per GPU" if world > 1 else "single GPU"},
+                   "strategy": args.strategy, "parallelism": "replica per GPU" if world > 1 else "single GPU",
+                   **({"graph_steps": True} if args.graph_steps else {})},
         "model_build_s": round(build_s, 1),
     }
     if host["steps"]:

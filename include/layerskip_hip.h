@@ -204,6 +204,9 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
 #define LSK_OPT_TARGET_WGS 2      /* workgroups per skinny projection launch (default 256) */
 #define LSK_OPT_FUSED_ATTN 3      /* 1 (default): page partials combined in-launch by the last arriver; 0: second kernel */
 #define LSK_OPT_FLASH_PREFILL 5   /* 1 (default): prompt rows use the flash-shaped prefill attention kernel; 0: 16-row decode passes */
+#define LSK_OPT_GRAPH_STEPS 7     /* 1: lsk_spec_generate replays its steady-state steps from hipGraphs (cached per speculation count
+                                     and KV page count) on a stream of the engine's own; identical tokens; default 0 -- the host is not
+                                     the limiter */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
 /* ---- sampling on the device (sample=True; GenerationConfig temperature / top_k / top_p, generator_base.py:35-44) ----
  * Both kernels are checked draw for draw against the oracle's model of them, and lsk_spec_step_sampled end to end against the

@@ -17,6 +17,7 @@ LSK_OPT_BIG_THRESHOLD = 1
 LSK_OPT_TARGET_WGS = 2
 LSK_OPT_FUSED_ATTN = 3
 LSK_OPT_FLASH_PREFILL = 5
+LSK_OPT_GRAPH_STEPS = 7       # steady-state greedy steps replayed from hipGraphs (default off)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "liblayerskip_hip.so")            # bf16 build (BASELINE configs)

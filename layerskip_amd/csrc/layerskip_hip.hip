@@ -228,6 +228,13 @@ struct lsk_engine {
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    // hipGraph replay of steady-state greedy steps (LSK_OPT_GRAPH_STEPS, default off: measured)
+    bool graph_steps = false;
+    int graph_pages = 0;          // > 0 while a step is captured / replayed: every attention launch covers this many pages
+    hipStream_t own_stream = nullptr;   // capture needs a non-default stream; torch's current stream is usually the null stream
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    struct StepGraph { int S, E, n_eos, slot, pages; hipGraphExec_t exec; };
+    std::vector<StepGraph> graphs;
     // host-side cost of the fused generate calls: time this thread spent enqueueing steps vs the wall time of the call
     double host_enqueue_s = 0.0, host_wall_s = 0.0;
     long long host_steps = 0;
@@ -422,6 +429,10 @@ extern "C" int lsk_engine_destroy(lsk_engine* e) {
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->host_result) (void)hipHostFree(e->host_result);
     for (int i = 0; i < 2; ++i) if (e->step_done[i]) (void)hipEventDestroy(e->step_done[i]);
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    if (e->join_ev) (void)hipEventDestroy(e->join_ev);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return 0;
 }
@@ -563,6 +574,7 @@ static int attn_params(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     sp.counters = e->fused_attn ? e->attn_cnt : nullptr; sp.out = out; sp.ldo = qdim;
     const int last_pos = e->kv_len_host + pos_off + m - 1;
     pages = last_pos / LSK_ATTN_PAGE + 1;
+    if (e->graph_pages > pages) pages = e->graph_pages;    // a captured step launches one page count for all its attention launches
     if (pages > e->n_pages) return lsk_fail("attention reaches page %d of %d", pages, e->n_pages);
     sp.n_pages = pages;
     // query heads of one KV head that share a workgroup (and one fetch of the page): as many as fit the 16 MFMA rows
@@ -836,7 +848,7 @@ static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, floa
 // kernel).  e->kv_len_host only has to be an UPPER bound (bounds checks, attention pages to launch).
 // sm != nullptr: sample=True -- every argmax becomes a draw from the warped distribution (decode_next_token,
 // llama_model_utils.py:123-131) and the prefix match becomes modified rejection sampling (SSG:191-199), on the device.
-static int enqueue_step(lsk_engine* e, int P, int S, int E, int n_eos, int slot, hipStream_t st, const StepSampling* sm = nullptr) {
+static int enqueue_step_body(lsk_engine* e, int P, int S, int E, int n_eos, int slot, hipStream_t st, const StepSampling* sm) {
     const lsk_config& c = e->cfg;
     const int L = c.num_layers;
     if (e->kv_len_host + P + S > c.max_ctx) return lsk_fail("context overflow: %d + %d + %d > max_ctx %d", e->kv_len_host, P, S, c.max_ctx);
@@ -884,6 +896,43 @@ static int enqueue_step(lsk_engine* e, int P, int S, int E, int n_eos, int slot,
         HIP_OK(hipGetLastError());
     }
     HIP_OK(hipMemcpyAsync(e->host_result + slot * 64, dres, sizeof(int) * LSK_RES_INTS, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+// A steady-state greedy step (P == 1) replayed from a hipGraph.  Everything a step needs lives on the device (kv_len, the next
+// input token), so its launches are identical from step to step except for the number of KV pages the attention launches
+// cover: graphs are cached per (S, E, n_eos, result slot, page count), the page count being an upper bound for the whole step
+// (page workgroups beyond a row's reach are masked out and never read by the combine).
+static int enqueue_step_graph(lsk_engine* e, int S, int E, int n_eos, int slot, hipStream_t st) {
+    const int pages = (e->kv_len_host + S) / LSK_ATTN_PAGE + 1;
+    if (pages > e->n_pages) return lsk_fail("context overflow while replaying a step graph");
+    hipGraphExec_t exec = nullptr;
+    for (const auto& g : e->graphs)
+        if (g.S == S && g.E == E && g.n_eos == n_eos && g.slot == slot && g.pages == pages) { exec = g.exec; break; }
+    if (exec == nullptr) {
+        hipGraph_t graph = nullptr;
+        e->graph_pages = pages;
+        HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_step_body(e, 1, S, E, n_eos, slot, st, nullptr);
+        const hipError_t err = hipStreamEndCapture(st, &graph);
+        e->graph_pages = 0;
+        if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (err != hipSuccess) return lsk_fail("hipStreamEndCapture failed: %s", hipGetErrorString(err));
+        const hipError_t ierr = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ierr != hipSuccess) return lsk_fail("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
+        e->graphs.push_back({S, E, n_eos, slot, pages, exec});
+    }
+    HIP_OK(hipGraphLaunch(exec, st));
+    return 0;
+}
+
+static int enqueue_step(lsk_engine* e, int P, int S, int E, int n_eos, int slot, hipStream_t st, const StepSampling* sm = nullptr) {
+    if (e->graph_steps && P == 1 && sm == nullptr && !e->profile && st == e->own_stream && e->kv_len_host + 1 + S <= e->cfg.max_ctx) {
+        LSK_TRY(enqueue_step_graph(e, S, E, n_eos, slot, st));
+    } else {
+        LSK_TRY(enqueue_step_body(e, P, S, E, n_eos, slot, st, sm));
+    }
     HIP_OK(hipEventRecord(e->step_done[slot], st));
     return 0;
 }
@@ -935,8 +984,22 @@ static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t 
                               int32_t* out_tokens, int32_t* n_out, int32_t* total_matches, int32_t* total_drafts,
                               int32_t* step_drafts, int32_t* step_matches, int32_t* n_steps, void* stream, const StepSampling* sm_base) {
     LSK_TRY(ready(e));
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
+    hipStream_t st = caller;
     if (!prompt_ids || !out_tokens || !n_out || !total_matches || !total_drafts) return lsk_fail("lsk_spec_generate: null pointer");
+    if (e->graph_steps && sm_base == nullptr) {
+        // stream capture is not allowed on the null stream (torch's default): the generation runs on the engine's own stream,
+        // ordered after the caller's stream at entry; the call is synchronous at return, so nothing has to be joined back
+        if (!e->own_stream) {
+            HIP_OK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
+        }
+        HIP_OK(hipEventRecord(e->fork_ev, caller));
+        HIP_OK(hipStreamWaitEvent(e->own_stream, e->fork_ev, 0));
+        st = e->own_stream;
+        stream = (void*)st;
+    }
     if (max_steps < 1) return lsk_fail("max_steps %d < 1", max_steps);
     const int S = num_speculations < 0 ? 0 : num_speculations;
     LSK_TRY(validate_step_args(e, prompt_len, S, exit_layer, eos_token_ids, n_eos));
@@ -1228,6 +1291,7 @@ extern "C" int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t valu
         case LSK_OPT_TARGET_WGS: e->target_wgs = value > 0 ? value : 256; return 0;
         case LSK_OPT_FUSED_ATTN: e->fused_attn = value != 0; return 0;
         case LSK_OPT_FLASH_PREFILL: e->flash_prefill = value != 0; return 0;
+        case LSK_OPT_GRAPH_STEPS: e->graph_steps = value != 0; return 0;
         default: return lsk_fail("unknown option %d", option);
     }
 }

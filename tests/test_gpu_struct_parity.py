@@ -177,3 +177,28 @@ def test_prefill_kernels_follow_the_reference_too(gpu_device):
         stats.add(buf[0, row["idx"]].cpu().tolist(), row)
     eng.reset()
     print(stats.check("tiny_gqa_long via the prefill kernels", strict=False))
+
+
+@pytest.mark.parametrize("name", ["tiny_gqa", "tiny_gqa_long", "tiny_mha_eos", "slice7b"])
+def test_graph_replayed_steps_give_the_same_generation(gpu_device, name):
+    """LSK_OPT_GRAPH_STEPS: steady-state steps replayed from hipGraphs (cached per speculation count and KV page count, on a
+    stream of the engine's own) -- same ids, same trace, same acceptance as the reference; and the engine is left usable."""
+    from layerskip_amd import _lib
+    from layerskip_amd.engine import get_engine
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    rec = load_struct(name)
+    gold = rec["bf16"]
+    model = _model(rec, gpu_device)
+    eng = get_engine(model)
+    spec = HipSelfSpeculativeGenerationStrategy()
+    try:
+        eng.set_option(_lib.LSK_OPT_GRAPH_STEPS, 1)
+        for _ in range(2):           # second pass: every graph comes from the cache
+            res = spec.generate_token_ids(model, rec["prompt"], rec["eos_token_ids"], _cfg(rec, "self_speculative"))
+            assert res.predicted_tokens == gold["spec_tokens"]
+            assert [list(s) for s in spec.last_steps] == gold["steps"]
+            assert res.acceptance_rate == gold["acceptance_rate"]
+    finally:
+        eng.set_option(_lib.LSK_OPT_GRAPH_STEPS, 0)
+    res = spec.generate_token_ids(model, rec["prompt"], rec["eos_token_ids"], _cfg(rec, "self_speculative"))
+    assert res.predicted_tokens == gold["spec_tokens"]
