@@ -53,8 +53,8 @@ def parse_args():
                          "throughput an extra key; replica / pp: only that one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-new-tokens", type=int, default=48)
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--cpu-prompt-len", type=int, default=64)
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0)
+    ap.add_argument("--cpu-prompt-len", type=int, default=512)
     ap.add_argument("--no-gpu-reference", action="store_true",
                     help="skip the leg that times the reference algorithm on THIS GPU (torch-ROCm eager ops)")
     ap.add_argument("--gpu-reference", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling: now the default
@@ -404,6 +404,7 @@ def cpu_baseline(args, cfg, model, E, S, strategy, eos):
     out, past, ids = [], None, torch.tensor([prompt])
     matches = drafts = 0
     margins = []
+    first_s, first_tokens = None, 0
     with torch.inference_mode():
         t0 = time.time()
         while len(out) < n_new and (time.time() - t0) < budget_s:
@@ -411,7 +412,10 @@ def cpu_baseline(args, cfg, model, E, S, strategy, eos):
                 om, ids, prompt, out, min(S, n_new - len(out) - 1), past, eos, E, margins)
             matches += n
             drafts += td
+            if first_s is None:
+                first_s, first_tokens = time.time() - t0, len(out)      # the step that carries the prompt prefill
         cpu_s = time.time() - t0
+    decode_only = (len(out) - first_tokens) / (cpu_s - first_s) if (first_s is not None and cpu_s > first_s and len(out) > first_tokens) else None
     gen = GenerationConfig(max_steps=len(out), exit_layer=E, num_speculations=S, sample=False,
                            generation_strategy="self_speculative")
     from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
@@ -421,6 +425,7 @@ def cpu_baseline(args, cfg, model, E, S, strategy, eos):
     from layerskip_amd.engine import BUF_BULK, get_engine
     eng = get_engine(model)
     seq = list(prompt) + list(out)
+    eng.ensure_capacity(len(seq) + 16, len(seq))
     eng.reset()
     eng.embed_rows(seq, BUF_BULK, 0)
     eng.run_bulk(len(seq), 0, eng.num_layers)
@@ -432,8 +437,9 @@ def cpu_baseline(args, cfg, model, E, S, strategy, eos):
     miss = [i for i in range(len(out)) if pred[P - 1 + i] != out[i]]
     return {"value": round(len(out) / cpu_s, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"1 prompt of {args.cpu_prompt_len} tokens, {len(out)} new tokens (budget {budget_s:.0f} s), same weights, "
-                      f"bf16, torch CPU {threads} threads of {cores} cores, {cpu_s:.1f} s "
-                      f"(weights D2H {copy_s:.1f} s not counted)",
+                      f"bf16, torch CPU {threads} threads of {cores} cores, {cpu_s:.1f} s of which {first_s:.1f} s in the first step "
+                      f"(prompt prefill); weights D2H {copy_s:.1f} s not counted",
+            "decode_only_tokens_per_s": None if decode_only is None else round(decode_only, 3),
             "acceptance_rate": round(matches / drafts, 4) if drafts else None,
             "parity_vs_gpu": {"free_running_first_mismatch": first,
                               "oracle_margin_there": None if first is None or first >= len(margins) else round(margins[first], 4),
