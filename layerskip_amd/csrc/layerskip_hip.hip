@@ -691,24 +691,54 @@ static int embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, elem_t* d
     return 0;
 }
 
-#ifndef LSK_BIG_NTW_WIDE
-#define LSK_BIG_NTW_WIDE 2        // 16-column tiles per wave of the q/k/v and gate/up prefill launches (4: one wave per SIMD, 2x slower)
+#ifndef LSK_PF_RT
+#define LSK_PF_RT 2               // 16-row query tiles per workgroup of the prefill attention kernel (lsk_attn.h)
 #endif
-
-template <int EPI, int NTW>
-static int launch_big(BigGemmParams& p, hipStream_t st) {
-    const int rb = (p.M + LSK_BIG_BM - 1) / LSK_BIG_BM;                    // row blocks
-    const int panels = (p.n_tiles + 4 * NTW - 1) / (4 * NTW);              // weight panels of 4 * NTW tiles
-    const dim3 grid(rb * 8 * ((panels + 7) / 8));                          // XCD-aware 1-D map: lsk_gemm_big.h
-    hipLaunchKernelGGL((lsk_gemm_big_kernel<EPI, NTW>), grid, dim3(LSK_BIG_THREADS), 0, st, p);
+#ifndef LSK_PF_PREFETCH
+#define LSK_PF_PREFETCH 0         // fragments requested one 32-key sub-block ahead: 0 none, 1 K, 2 K and V^T (measured: no gain, fewer waves)
+#endif
+static int launch_attn_prefill(const AttnPrefillParams& ap, int n_heads, int head_dim, int rows, hipStream_t st) {
+    const dim3 grid(n_heads, (rows + 16 * LSK_PF_RT - 1) / (16 * LSK_PF_RT)), block(LSK_ATTN_THREADS);
+    if (head_dim == 128) hipLaunchKernelGGL((lsk_attn_prefill_kernel<128, LSK_PF_RT, LSK_PF_PREFETCH>), grid, block, 0, st, ap);
+    else hipLaunchKernelGGL((lsk_attn_prefill_kernel<64, LSK_PF_RT, LSK_PF_PREFETCH>), grid, block, 0, st, ap);
     HIP_OK(hipGetLastError());
     return 0;
 }
 
-// N = hidden projections: 128-column tiles only when they already give >= 256 workgroups, else 64-column tiles
+// Prefill tile shapes (lsk_gemm_big.h): NTW 16-column tiles per wave x MT 16-row tiles per workgroup x NW waves, weight ring PB
+// K-tiles deep.  Chosen per projection and prompt length from rocprofv3 kernel times at 511 and 2047 rows:
+//   gate/up     : 128 x 128 tile, ring 2 (164 registers: three waves per SIMD; ring 4 holds two);
+//   q/k/v       : 64-row tiles (a 512-row prompt gives 768 workgroups, one full round at three per CU); eight waves (64 x 256)
+//                 once the prompt is long enough to fill the chip with those;
+//   o_proj/down : N = hidden gives 128 workgroups of 128 x 128 for 256 CUs at 512 rows: 64 x 128 tiles, ring 4, pinned
+//                 activation requests; the 128 x 128 tile once that already gives two workgroups per CU.
+template <int EPI, int NTW, int MT, int PB, int NW, bool PIN>
+static int launch_big_pb(BigGemmParams& p, hipStream_t st) {
+    const int rb = (p.M + MT * 16 - 1) / (MT * 16);                        // row blocks
+    const int panels = (p.n_tiles + NW * NTW - 1) / (NW * NTW);            // weight panels of NW * NTW tiles
+    const dim3 grid(rb * 8 * ((panels + 7) / 8));                          // XCD-aware 1-D map: lsk_gemm_big.h
+    hipLaunchKernelGGL((lsk_gemm_big_kernel<EPI, NTW, MT, PB, NW, PIN>), grid, dim3(NW * 64), 0, st, p);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// PB = the deepest weight ring of {PBMAX, 2} that divides the number of K-tiles (K is a multiple of 128: run_bulk)
+template <int EPI, int NTW, int MT, int PBMAX, int NW, bool PIN>
+static int launch_big(BigGemmParams& p, hipStream_t st) {
+    const int nkt = p.K / LSK_BIG_BK;
+    if (PBMAX == 4 && nkt % 4 == 0) return launch_big_pb<EPI, NTW, MT, 4, NW, PIN>(p, st);
+    return launch_big_pb<EPI, NTW, MT, 2, NW, PIN>(p, st);
+}
+
+static int launch_big_qkv(BigGemmParams& p, hipStream_t st) {
+    return p.M > 1024 ? launch_big<EPI_QKV, 2, 4, 2, 8, false>(p, st) : launch_big<EPI_QKV, 2, 4, 2, 4, false>(p, st);
+}
+
+static int launch_big_gateup(BigGemmParams& p, hipStream_t st) { return launch_big<EPI_SWIGLU, 2, 8, 2, 4, false>(p, st); }
+
 static int launch_big_resid(BigGemmParams& p, hipStream_t st) {
-    const int wgs128 = ((p.M + LSK_BIG_BM - 1) / LSK_BIG_BM) * ((p.n_tiles + 7) / 8);
-    return wgs128 >= 256 ? launch_big<EPI_RESID, 2>(p, st) : launch_big<EPI_RESID, 1>(p, st);
+    const int wgs128 = ((p.M + 127) / 128) * ((p.n_tiles + 7) / 8);
+    return wgs128 >= 512 ? launch_big<EPI_RESID, 2, 8, 2, 4, false>(p, st) : launch_big<EPI_RESID, 2, 4, 4, 4, true>(p, st);
 }
 
 // Prompt rows [0, n) of the bulk buffer through layers [lb, le) with the MFMA-tiled prefill kernels.
@@ -729,17 +759,14 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
             p.q_out = e->q_bulk; p.ldq = qdim; p.kpool = kpool; p.vpool = vpool; p.block_table = e->block_table; p.page_size = c.page_size;
             p.n_heads = c.n_heads; p.n_kv = c.n_kv_heads; p.head_dim = c.head_dim; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
             p.kv_len = kvp; p.pos_off = 0;
-            LSK_TRY((launch_big<EPI_QKV, LSK_BIG_NTW_WIDE>(p, st)));
+            LSK_TRY(launch_big_qkv(p, st));
         }
         if (e->flash_prefill) {
             AttnPrefillParams ap{};
             ap.q = e->q_bulk; ap.ldq = qdim; ap.out = e->attn_bulk; ap.ldo = qdim; ap.kpool = kpool; ap.vpool = vpool;
             ap.block_table = e->block_table; ap.n_kv = c.n_kv_heads; ap.group = c.n_heads / c.n_kv_heads; ap.rows = n;
             ap.kv_len = kvp; ap.pos_off = 0; ap.scale_log2e = (float)((1.0 / sqrt((double)c.head_dim)) * 1.4426950408889634);
-            const dim3 grid(c.n_heads, (n + 15) / 16), block(LSK_ATTN_THREADS);
-            if (c.head_dim == 128) hipLaunchKernelGGL((lsk_attn_prefill_kernel<128>), grid, block, 0, st, ap);
-            else hipLaunchKernelGGL((lsk_attn_prefill_kernel<64>), grid, block, 0, st, ap);
-            HIP_OK(hipGetLastError());
+            LSK_TRY(launch_attn_prefill(ap, c.n_heads, c.head_dim, n, st));
         } else {
             for (int r0 = 0; r0 < n; r0 += LSK_MAX_ROWS) {
                 const int m = (n - r0) < LSK_MAX_ROWS ? (n - r0) : LSK_MAX_ROWS;
@@ -758,7 +785,7 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
             BigGemmParams p{};
             p.x = e->xn_bulk; p.ldx = c.hidden; p.M = n; p.K = c.hidden; p.wp = lw.wgu; p.N = 2 * c.intermediate; p.n_tiles = p.N / 16;
             p.act = e->act_bulk; p.ldact = c.intermediate;
-            LSK_TRY((launch_big<EPI_SWIGLU, LSK_BIG_NTW_WIDE>(p, st)));
+            LSK_TRY(launch_big_gateup(p, st));
         }
         {
             BigGemmParams p{};
@@ -774,7 +801,7 @@ static int run_bulk_big(lsk_engine* e, int n, int lb, int le, hipStream_t st) {
 // MFMA-tiled prefill kernels for real prompts, 16-row passes of the decode kernels for short ones.
 static int run_bulk(lsk_engine* e, int n, const int* base_ptr, int lb, int le, hipStream_t st) {
     const lsk_config& c = e->cfg;
-    const int kq = LSK_BIG_BK * LSK_BIG_PB;      // the prefill kernel walks K in runs of LSK_BIG_PB tiles
+    const int kq = LSK_BIG_BK * 2;               // the prefill kernel walks K in runs of >= 2 tiles
     const bool big_ok = (c.hidden % kq == 0) && ((c.n_heads * c.head_dim) % kq == 0) && (c.intermediate % kq == 0);
     if (n >= e->big_threshold && big_ok) return run_bulk_big(e, n, lb, le, st);
     for (int r0 = 0; r0 < n; r0 += LSK_MAX_ROWS) {
@@ -1560,11 +1587,7 @@ extern "C" int lsk_test_attention(const void* q, int32_t rows, int32_t n_heads, 
         ap.q = (const elem_t*)q; ap.ldq = qdim; ap.out = (elem_t*)out; ap.ldo = qdim; ap.kpool = (const elem_t*)kpool; ap.vpool = (const elem_t*)vpool;
         ap.block_table = block_table_dev; ap.n_kv = n_kv_heads; ap.group = n_heads / n_kv_heads; ap.rows = rows;
         ap.kv_len = kv_len_dev; ap.pos_off = pos_off; ap.scale_log2e = scale;
-        const dim3 grid(n_heads, (rows + 15) / 16), block(LSK_ATTN_THREADS);
-        if (head_dim == 128) hipLaunchKernelGGL((lsk_attn_prefill_kernel<128>), grid, block, 0, st, ap);
-        else hipLaunchKernelGGL((lsk_attn_prefill_kernel<64>), grid, block, 0, st, ap);
-        HIP_OK(hipGetLastError());
-        return 0;
+        return launch_attn_prefill(ap, n_heads, head_dim, rows, st);
     }
     size_t need = 0;
     LSK_TRY(lsk_test_attention_scratch_bytes(n_heads, head_dim, max_pages, &need));

@@ -302,12 +302,16 @@ __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineP
     p.out[(size_t)row * p.ldo + head * HD + d] = f2e(a / l);
 }
 
-// ---- prompt-prefill attention: 16 query rows x all visible keys per workgroup, online softmax (flash shape) ----
-// grid = (n_heads, ceil(rows / 16)), block = 4 waves.  Wave w walks KV pages w, w+4, ... of its head in 32-key
+// ---- prompt-prefill attention: RT x 16 query rows x all visible keys per workgroup, online softmax (flash shape) ----
+// grid = (n_heads, ceil(rows / (16 RT))), block = 4 waves.  Wave w walks KV pages w, w+4, ... of its head in 32-key
 // sub-blocks: K / V^T fragments straight from the pages (same layouts as the decode kernel), S = QK^T and
 // O += P V on MFMA, running (max, sum) per row with one rescale of O per sub-block, P rounded to bf16 through
-// 1 KiB of LDS per wave.  The 4 waves are merged in a fixed order at the end.  One launch per layer replaces the
-// rows/16 launches of the decode kernel; only prompt rows that are not decision rows go through it.
+// LDS.  The RT row tiles of a workgroup share every K / V^T fragment a wave loads (the kernel is bound by those
+// fragment-shaped L2 reads, not by the MFMAs: RT = 2 halves them); PF selects what is requested one sub-block ahead.  The 4 waves are merged in a fixed order at the end, one row tile at a time.
+// A row's arithmetic depends only on its position (key partition by page, fixed sub-block order): a row tile for
+// which a sub-block lies entirely in the future multiplies its accumulators by exp2(0) = 1 and adds P = 0 products,
+// so results are bit-identical for every RT.  One launch per layer replaces the rows/16 launches of the decode
+// kernel; only prompt rows that are not decision rows go through it.
 struct AttnPrefillParams {
     const elem_t* q;        // [rows][ldq]
     int ldq;
@@ -324,78 +328,97 @@ struct AttnPrefillParams {
     float scale_log2e;
 };
 
-template <int HD>
-__global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(const AttnPrefillParams p) {
+#ifndef LSK_PF_MINW
+#define LSK_PF_MINW 2               // min waves per SIMD: keeps hipcc inside 256 registers WITHOUT parking values in AGPRs (218 + 64 -> 222 + 0)
+#endif
+template <int HD, int RT, int PF>
+__global__ __launch_bounds__(LSK_ATTN_THREADS, LSK_PF_MINW) void lsk_attn_prefill_kernel(const AttnPrefillParams p) {
     constexpr int KS = HD / 32;
     constexpr int DT = HD / 16;
     constexpr int PSTRIDE = HD + 2;
     constexpr int PB_STRIDE = 80;
-    __shared__ __attribute__((aligned(16))) unsigned char pbuf[LSK_ATTN_WAVES * 16 * PB_STRIDE];
+    constexpr int RB = RT * 16;              // query rows per workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char pbuf[LSK_ATTN_WAVES * RB * PB_STRIDE];
     __shared__ float sm[LSK_ATTN_WAVES * 16 * PSTRIDE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = blockIdx.x;
-    const int r0 = blockIdx.y * 16;
+    const int r0 = blockIdx.y * RB;
     const int kvh = head / p.group;
     const int c16 = lane & 15;
     const int g = lane >> 4;
     const int base_pos = *p.kv_len + p.pos_off + r0;          // position of this workgroup's first row
-    const int M = min(16, p.rows - r0);
+    const int M = min(RB, p.rows - r0);
     const int last_key = base_pos + M - 1;
     const int n_pages = last_key / LSK_ATTN_PAGE + 1;
 
-    const elem_t* qp = p.q + (size_t)(r0 + min(c16, M - 1)) * p.ldq + head * HD + g * 8;
-    elem8 qa[KS];
+    elem8 qa[RT][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qa[ks] = *(const elem8*)(qp + ks * 32);
+    for (int rt = 0; rt < RT; ++rt) {
+        const elem_t* qp = p.q + (size_t)(r0 + min(rt * 16 + c16, M - 1)) * p.ldq + head * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qa[rt][ks] = *(const elem8*)(qp + ks * 32);
+    }
 
-    float mrun[4], lrun[4];
-    f32x4 o[DT];
+    float mrun[RT][4], lrun[RT][4];
+    f32x4 o[RT][DT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { mrun[r] = LSK_ATTN_NEG; lrun[r] = 0.f; }
+    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    unsigned char* pw = pbuf + w * 16 * PB_STRIDE;
+        for (int r = 0; r < 4; ++r) { mrun[rt][r] = LSK_ATTN_NEG; lrun[rt][r] = 0.f; }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[rt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    unsigned char* pw = pbuf + w * RB * PB_STRIDE;
 
-    for (int pg = w; pg < n_pages; pg += LSK_ATTN_WAVES) {
-        const int page = p.block_table[pg];
-        const size_t head_base = ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD;
-        for (int sb = 0; sb < 4; ++sb) {
-            const int key0 = pg * LSK_ATTN_PAGE + sb * 32;
-            if (key0 > last_key) break;
-            const elem_t* kp = p.kpool + head_base + (size_t)(sb * 32 + c16) * HD + g * 8;
-            const elem_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + sb * 32 + g * 8;
-            elem8 kb[2][KS], vb[DT];
+    // this wave's sub-blocks, flattened: j -> page w + 4 (j / 4), 32-key sub-block j % 4; only the last page in reach is partial
+    const int my_pages = (n_pages > w) ? (n_pages - w + LSK_ATTN_WAVES - 1) / LSK_ATTN_WAVES : 0;
+    const bool own_last = my_pages > 0 && ((n_pages - 1 - w) % LSK_ATTN_WAVES == 0);
+    const int nj = my_pages * 4 - (own_last ? 3 - ((last_key - (n_pages - 1) * LSK_ATTN_PAGE) >> 5) : 0);
+    // PF = what is requested one sub-block ahead: 0 nothing, 1 the K fragments, 2 K and V^T (64 more registers at d = 128)
+    elem8 kb[PF >= 1 ? 2 : 1][2][KS], vb[PF == 2 ? 2 : 1][DT];
+    auto load_k = [&](int j, elem8 (&kd)[2][KS]) {      // unconditional: j is clamped by the caller
+        const int page = p.block_table[w + LSK_ATTN_WAVES * (j >> 2)];
+        const elem_t* kp = p.kpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)((j & 3) * 32 + c16) * HD + g * 8;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                kb[0][ks] = *(const elem8*)(kp + ks * 32);
-                kb[1][ks] = *(const elem8*)(kp + 16 * HD + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) {
+            kd[0][ks] = *(const elem8*)(kp + ks * 32);
+            kd[1][ks] = *(const elem8*)(kp + 16 * HD + ks * 32);
+        }
+    };
+    auto load_v = [&](int j, elem8 (&vd)[DT]) {
+        const int page = p.block_table[w + LSK_ATTN_WAVES * (j >> 2)];
+        const elem_t* vp = p.vpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)c16 * LSK_ATTN_PAGE + (j & 3) * 32 + g * 8;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vd[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
+    };
+    auto block = [&](int j, elem8 (&kd)[2][KS], elem8 (&vd)[DT]) {
+        const int key0 = (w + LSK_ATTN_WAVES * (j >> 2)) * LSK_ATTN_PAGE + (j & 3) * 32;
+        {   // never-written slots behind this block's last key may hold NaN: zero their V (see lsk_attn_body)
+            const int nvalid = last_key + 1 - (key0 + g * 8);
+            if (nvalid < 8) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj)
+                        if (jj >= nvalid) vd[dt][jj] = (elem_t)0.0f;
             }
+        }
+        const int keyA = key0 + c16;
+        float alpha[RT][4];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
-            {   // never-written slots behind this block's last key may hold NaN: zero their V (see lsk_attn_body)
-                const int nvalid = last_key + 1 - (key0 + g * 8);
-                if (nvalid < 8) {
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (j >= nvalid) vb[dt][j] = (elem_t)0.0f;
-                }
-            }
+        for (int rt = 0; rt < RT; ++rt) {
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s0 = LSK_MFMA_16x16x32(qa[ks], kb[0][ks], s0, 0, 0, 0);
-                s1 = LSK_MFMA_16x16x32(qa[ks], kb[1][ks], s1, 0, 0, 0);
+                s0 = LSK_MFMA_16x16x32(qa[rt][ks], kd[0][ks], s0, 0, 0, 0);
+                s1 = LSK_MFMA_16x16x32(qa[rt][ks], kd[1][ks], s1, 0, 0, 0);
             }
-            const int keyA = key0 + c16;
-            float alpha[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = g * 4 + r;
+                const int row = rt * 16 + g * 4 + r;
                 const int lim = base_pos + row;
                 const bool ok0 = (row < M) && (keyA <= lim);
                 const bool ok1 = (row < M) && (keyA + 16 <= lim);
@@ -403,57 +426,88 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_prefill_kernel(cons
                 const float a1 = ok1 ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
                 float m = fmaxf(a0, a1);
                 m = row16_max(m);
-                const float mn = fmaxf(mrun[r], m);
-                alpha[r] = __builtin_amdgcn_exp2f(mrun[r] - mn);
+                const float mn = fmaxf(mrun[rt][r], m);
+                alpha[rt][r] = __builtin_amdgcn_exp2f(mrun[rt][r] - mn);
                 const float p0 = ok0 ? __builtin_amdgcn_exp2f(a0 - mn) : 0.f;
                 const float p1 = ok1 ? __builtin_amdgcn_exp2f(a1 - mn) : 0.f;
                 float l = p0 + p1;
                 l = row16_sum(l);
-                lrun[r] = lrun[r] * alpha[r] + l;
-                mrun[r] = mn;
+                lrun[rt][r] = lrun[rt][r] * alpha[rt][r] + l;
+                mrun[rt][r] = mn;
                 *(elem_t*)(pw + row * PB_STRIDE + c16 * 2) = f2e(p0);
                 *(elem_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2e(p1);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const elem8 pa = *(const elem8*)(pw + c16 * PB_STRIDE + g * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const elem8 pa = *(const elem8*)(pw + (rt * 16 + c16) * PB_STRIDE + g * 16);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha[r];
-                o[dt] = LSK_MFMA_16x16x32(pa, vb[dt], o[dt], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) o[rt][dt][r] *= alpha[rt][r];
+                o[rt][dt] = LSK_MFMA_16x16x32(pa, vd[dt], o[rt][dt], 0, 0, 0);
             }
-            __builtin_amdgcn_wave_barrier();     // P of the next sub-block must not overwrite before the read above
+        }
+        __builtin_amdgcn_wave_barrier();     // P of the next sub-block must not overwrite before the reads above
+    };
+    if (PF == 0) {
+        for (int j = 0; j < nj; ++j) {
+            load_k(j, kb[0]);
+            load_v(j, vb[0]);
+            block(j, kb[0], vb[0]);
+        }
+    } else if (nj > 0) {
+        constexpr int K1 = PF >= 1 ? 1 : 0, V1 = PF == 2 ? 1 : 0;
+        load_k(0, kb[0]);
+        if (PF == 2) load_v(0, vb[0]);
+        for (int j = 0; j < nj; j += 2) {
+            if (PF == 1) load_v(j, vb[0]);
+            load_k(min(j + 1, nj - 1), kb[K1]);
+            if (PF == 2) load_v(min(j + 1, nj - 1), vb[V1]);
+            block(j, kb[0], vb[0]);
+            if (j + 1 >= nj) break;
+            if (PF == 1) load_v(j + 1, vb[0]);
+            load_k(min(j + 2, nj - 1), kb[0]);
+            if (PF == 2) load_v(min(j + 2, nj - 1), vb[0]);
+            block(j + 1, kb[K1], vb[V1]);
         }
     }
+    // ---- merge the 4 waves (fixed order), one row tile at a time through 4 x 16 x (HD + 2) floats of LDS ----
     float* dst = sm + (size_t)w * 16 * PSTRIDE;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int rt = 0; rt < RT; ++rt) {
+        if (rt) __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(g * 4 + r) * PSTRIDE + dt * 16 + c16] = o[dt][r];
-    if (c16 == 0) {
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dst[(g * 4 + r) * PSTRIDE + HD] = mrun[r];
-            dst[(g * 4 + r) * PSTRIDE + HD + 1] = lrun[r];
+            for (int r = 0; r < 4; ++r) dst[(g * 4 + r) * PSTRIDE + dt * 16 + c16] = o[rt][dt][r];
+        if (c16 == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dst[(g * 4 + r) * PSTRIDE + HD] = mrun[rt][r];
+                dst[(g * 4 + r) * PSTRIDE + HD + 1] = lrun[rt][r];
+            }
         }
-    }
-    __syncthreads();
-    for (int e = tid; e < M * HD; e += LSK_ATTN_THREADS) {
-        const int r = e / HD;
-        const int d = e - r * HD;
-        float m = LSK_ATTN_NEG;
+        __syncthreads();
+        const int mt = min(16, M - rt * 16);
+        for (int e = tid; e < mt * HD; e += LSK_ATTN_THREADS) {
+            const int r = e / HD;
+            const int d = e - r * HD;
+            float m = LSK_ATTN_NEG;
 #pragma unroll
-        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + r) * PSTRIDE + HD]);
-        float a = 0.f, l = 0.f;
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + r) * PSTRIDE + HD]);
+            float a = 0.f, l = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
-            const float* src = sm + (ww * 16 + r) * PSTRIDE;
-            const float f = __builtin_amdgcn_exp2f(src[HD] - m);
-            a += src[d] * f;
-            l += src[HD + 1] * f;
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
+                const float* src = sm + (ww * 16 + r) * PSTRIDE;
+                const float f = __builtin_amdgcn_exp2f(src[HD] - m);
+                a += src[d] * f;
+                l += src[HD + 1] * f;
+            }
+            p.out[(size_t)(r0 + rt * 16 + r) * p.ldo + head * HD + d] = f2e(a / l);
         }
-        p.out[(size_t)(r0 + r) * p.ldo + head * HD + d] = f2e(a / l);
     }
 }

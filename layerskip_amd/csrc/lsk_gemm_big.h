@@ -14,15 +14,7 @@
 #pragma once
 #include "lsk_common.h"
 
-#define LSK_BIG_BM 128
 #define LSK_BIG_BK 64
-#define LSK_BIG_THREADS 256
-#ifndef LSK_BIG_PB
-#define LSK_BIG_PB 2             // K-tiles of weight fragments in flight per wave (even; 4 and 6 measured no faster)
-#endif
-#ifndef LSK_BIG_ALINE
-#define LSK_BIG_ALINE 1          // activation staging loads whole 128-byte lines (8 lanes per row) instead of 64 bytes per thread
-#endif
 #define LSK_BIG_LDA 160          // bytes per LDS row: 64 bf16 + 32 B pad (slot (10r + g) mod 16: conflict-free A-fragment reads)
 
 struct BigGemmParams {
@@ -56,10 +48,19 @@ struct BigGemmParams {
 };
 
 // NTW = packed 16-column tiles per wave: 4 or 2 (256- / 128-column workgroup tile; SwiGLU needs the gate/up PAIRS in one wave) or
-// 1 (64-column tile: twice the workgroups for the N = hidden projections, which otherwise fill half the chip).
-template <int EPI, int NTW>
-__global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const BigGemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * LSK_BIG_BM * LSK_BIG_LDA];
+// 1 (64-column tile).  MT = 16-row tiles per workgroup (BM = 16 MT rows: 128, 64 or 32).  Every A fragment read from LDS feeds NTW
+// MFMAs and the LDS pipe is the first unit to saturate (one 1 KiB fragment read = 8 LDS cycles for 16 MFMA cycles, four SIMDs on one
+// LDS), so NTW sets the MFMA ceiling and MT x NTW the accumulator registers: (MT, NTW) = (8, 2) and (4, 4) both hold 64 accumulator
+// VGPRs at two waves per SIMD; (8, 4) needs 288 registers (one wave per SIMD, measured 2x slower).
+template <int EPI, int NTW, int MT, int PB, int NW, bool PIN>
+__global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmParams p) {
+    constexpr int BM = MT * 16;
+    constexpr int SR = NW * 8;                  // rows staged per pass (8 lanes per row)
+    constexpr int NP = BM / SR;                 // staging passes per K-tile
+    static_assert((NW == 4 || NW == 8) && NP >= 1, "waves per workgroup");
+    static_assert(MT == 2 || MT == 4 || MT == 8, "row tiles per workgroup");
+    static_assert(PB >= 2 && PB % 2 == 0, "weight ring depth (K-tiles in flight per wave): even");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * LSK_BIG_LDA];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,39 +69,30 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
     // is fetched from HBM RB times (measured: 730 MB per gate/up launch for 180 MB of weights, r02_pmc_hbm_traffic.csv).  Here
     // every run of RB x 8 consecutive ids holds 8 panels, panel = run * 8 + (id % 8), row block = (id % (RB*8)) / 8: the RB
     // workgroups of a panel share id % 8, i.e. one XCD and one L2 fetch, and are dispatched within one run of each other.
-    const int RB = (p.M + LSK_BIG_BM - 1) / LSK_BIG_BM;
+    const int RB = (p.M + BM - 1) / BM;
     const int run = blockIdx.x / (RB * 8);
     const int idx = blockIdx.x - run * (RB * 8);
     const int panel = run * 8 + (idx & 7);
-    const int m0 = (idx >> 3) * LSK_BIG_BM;
-    const int T0 = (panel * 4 + w) * NTW;               // this wave's first packed tile
-    if (panel * 4 * NTW >= p.n_tiles) return;           // padding of the last run
+    const int m0 = (idx >> 3) * BM;
+    const int T0 = (panel * NW + w) * NTW;               // this wave's first packed tile
+    if (panel * NW * NTW >= p.n_tiles) return;           // padding of the last run
     const int ksteps = p.K >> 5;
     const int nkt = p.K / LSK_BIG_BK;
     const bool tile_ok = T0 < p.n_tiles;
 
-#if LSK_BIG_ALINE
     // A staging: a K-tile row is ONE 128-byte line (64 bf16).  Eight lanes fetch a row's line with one 16-byte load each, a wave
     // instruction covers 8 whole lines (the texture addresser walks lines, not bytes: 64 bytes per thread over 32 rows cost 4x the
-    // address cycles for the same data); piece i of a thread is row (tid >> 3) + 32 i, 16-byte column tid & 7.
+    // address cycles for the same data); piece i of a thread is row (tid >> 3) + SR i, 16-byte column tid & 7.
     const int arow = tid >> 3;
     const int acol = tid & 7;
-    const elem_t* aptr_i[4];
-    unsigned char* awr_i[4];
+    const elem_t* aptr_i[NP];
+    unsigned char* awr_i[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = arow + 32 * i;
+    for (int i = 0; i < NP; ++i) {
+        const int r = arow + SR * i;
         aptr_i[i] = p.x + (size_t)min(m0 + r, p.M - 1) * p.ldx + acol * 8;
         awr_i[i] = lds + r * LSK_BIG_LDA + acol * 16;
     }
-#else
-    // A staging: thread -> (row, 64-byte half)
-    const int arow = tid >> 1;
-    const int ahalf = tid & 1;
-    const int grow = min(m0 + arow, p.M - 1);
-    const elem_t* aptr = p.x + (size_t)grow * p.ldx + ahalf * 32;
-    unsigned char* awr = lds + arow * LSK_BIG_LDA + ahalf * 64;
-#endif
     // B fragments: packed tile T, k-step s at ((T*ksteps + s)*64 + lane)*8 elements.  A wave whose tile lies beyond the matrix
     // (last panel of a ragged N) streams the last valid tile instead and drops the result: every load of the K loop is
     // UNCONDITIONAL -- a "tile ok ? load : zero" select makes hipcc branch around each load and fall back to s_waitcnt vmcnt(0)
@@ -109,36 +101,24 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) bptr[nt] = p.wp + ((size_t)min(T0 + nt, p.n_tiles - 1) * ksteps * 64 + lane) * 8;
 
-    f32x4 acc[8][NTW];
+    f32x4 acc[MT][NTW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Weight fragments: a register ring LSK_BIG_PB K-tiles deep per wave, refilled the moment a slot is consumed.  Activations:
+    // Weight fragments: a register ring PB K-tiles deep per wave, refilled the moment a slot is consumed.  Activations:
     // two register sets (tiles kt+1, kt+2) feeding the double-buffered LDS image.  Slot indices are static: the K loop is
     // unrolled by the ring depth, every load is unconditional, so every s_waitcnt in the loop is a COUNTED one.
-    elem8 aq[2][4];
-    elem8 bq[LSK_BIG_PB][NTW][2];
-    auto load_a = [&](int kt, elem8 (&dst)[4]) {
-#if LSK_BIG_ALINE
+    elem8 aq[2][NP];
+    elem8 bq[PB][NTW][2];
+    auto load_a = [&](int kt, elem8 (&dst)[NP]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = *(const elem8*)(aptr_i[i] + (size_t)kt * LSK_BIG_BK);
-#else
-        const elem_t* an = aptr + (size_t)kt * LSK_BIG_BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = *(const elem8*)(an + i * 8);
-#endif
+        for (int i = 0; i < NP; ++i) dst[i] = *(const elem8*)(aptr_i[i] + (size_t)kt * LSK_BIG_BK);
     };
-    auto store_a = [&](int buf, const elem8 (&src)[4]) {
-#if LSK_BIG_ALINE
+    auto store_a = [&](int buf, const elem8 (&src)[NP]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(elem8*)(awr_i[i] + buf * (LSK_BIG_BM * LSK_BIG_LDA)) = src[i];
-#else
-        unsigned char* dst = awr + buf * (LSK_BIG_BM * LSK_BIG_LDA);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(elem8*)(dst + i * 16) = src[i];
-#endif
+        for (int i = 0; i < NP; ++i) *(elem8*)(awr_i[i] + buf * (BM * LSK_BIG_LDA)) = src[i];
     };
     auto load_b = [&](int kt, elem8 (&dst)[NTW][2]) {
 #pragma unroll
@@ -148,34 +128,36 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
             for (int nt = 0; nt < NTW; ++nt) dst[nt][s] = *(const elem8*)(bptr[nt] + bo);
         }
     };
-    // nkt is a multiple of LSK_BIG_PB (the host takes the 16-row path otherwise); indices past the end are clamped to the last
+    // nkt is a multiple of PB (the host picks PB accordingly); indices past the end are clamped to the last
     // tile (a few redundant loads at the tail) so that the loop body has no data-dependent branch and every wait is counted
     const int last = nkt - 1;
+    const unsigned char* ard = lds + (lane & 15) * LSK_BIG_LDA + (lane >> 4) * 16;
     load_a(0, aq[0]);
     load_a(min(1, last), aq[1]);
 #pragma unroll
-    for (int u = 0; u < LSK_BIG_PB; ++u) load_b(min(u, last), bq[u]);
+    for (int u = 0; u < PB; ++u) load_b(min(u, last), bq[u]);
     store_a(0, aq[0]);
     __syncthreads();
-
-    const unsigned char* ard = lds + (lane & 15) * LSK_BIG_LDA + (lane >> 4) * 16;
-    for (int kt0 = 0; kt0 < nkt; kt0 += LSK_BIG_PB) {
+    for (int kt0 = 0; kt0 < nkt; kt0 += PB) {
 #pragma unroll
-        for (int u = 0; u < LSK_BIG_PB; ++u) {
+        for (int u = 0; u < PB; ++u) {
             const int kt = kt0 + u;
-            const int cur = u & 1;                            // LSK_BIG_PB is even: kt & 1 == u & 1
+            const int cur = u & 1;                            // PB is even: kt & 1 == u & 1
             load_a(min(kt + 2, last), aq[cur]);               // aq[cur] held tile kt: already in LDS
-            const unsigned char* abase = ard + cur * (LSK_BIG_BM * LSK_BIG_LDA);
+            // PIN: keep the activation request HERE, two K-tiles ahead of its LDS store (hipcc otherwise sinks it behind this
+            // tile's MFMAs, one K-tile ahead): pays on the N = hidden projections (61 -> 56 us), not on the wide ones
+            if (PIN) __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* abase = ard + cur * (BM * LSK_BIG_LDA);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const elem8 a = *(const elem8*)(abase + mt * 16 * LSK_BIG_LDA + s * 64);
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = LSK_MFMA_16x16x32(a, bq[u][nt][s], acc[mt][nt], 0, 0, 0);
                 }
             }
-            load_b(min(kt + LSK_BIG_PB, last), bq[u]);        // refill the slot just consumed
+            load_b(min(kt + PB, last), bq[u]);                // refill the slot just consumed
             store_a(cur ^ 1, aq[cur ^ 1]);                    // tile kt + 1 (loaded one iteration ago) -> the other LDS buffer
             __syncthreads();
         }
@@ -189,7 +171,7 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
         for (int nt = 0; nt < NTW; ++nt) {
             const int n = (T0 + nt) * 16 + c16;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = m0 + mt * 16 + rg * 4 + i;
@@ -204,7 +186,7 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
         for (int pr = 0; pr < NTW / 2; ++pr) {               // gate / up tiles are interleaved pairwise
             const int n = ((T0 >> 1) + pr) * 16 + c16;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = m0 + mt * 16 + rg * 4 + i;
@@ -231,7 +213,7 @@ __global__ __launch_bounds__(LSK_BIG_THREADS) void lsk_gemm_big_kernel(const Big
             const int head = TT / tph;
             const int tt = TT - head * tph;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = m0 + mt * 16 + rg * 4 + i;

@@ -31,5 +31,6 @@ for n in rows:
             eng.run_bulk(n, 0, eng.num_layers)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
-        print(f"rows {n} flash {flash}: {min(ts) * 1e3:.2f} ms", flush=True)
+        h = eng.rows_view(BUF_BULK, 0, n).view(torch.int16).to(torch.int64)          # bit pattern of the final hidden rows
+        print(f"rows {n} flash {flash}: {min(ts) * 1e3:.2f} ms  checksum {int((h * torch.arange(1, h.numel() + 1, device=h.device).view_as(h) % 1000003).sum().item())}", flush=True)
     eng.close()
