@@ -1,13 +1,17 @@
 // Prompt-prefill projection kernel: Y[M ~ 512][N] = X[M][K] @ W[N][K]^T on bf16 MFMA, same packed
 // weight tiles as the skinny decode kernel (so no second copy of the weights exists).
 //
-// MFMA-bound (M >= 128 rows => >= 128 FLOP per weight byte), one-off per generation (<= 2 % of the
-// path's time), so this is the plain LDS-tiled shape: 128-row x 128-column output tile per 4-wave
+// MFMA-shaped (M >= 128 rows => >= 128 FLOP per weight byte), one-off per generation (<= 2 % of the
+// path's time): the LDS-tiled shape.  (16 MT)-row x (16 NTW NW)-column output tile per NW-wave
 // workgroup, A tile (activations) staged through a double-buffered, padded LDS image, B fragments
-// (weights) straight from the packed tiles to VGPRs (each wave owns two adjacent 16-column tiles, i.e.
-// exactly one gate/up pair or one RoPE tile pair), register-prefetch of the next K-tile under the
-// current MFMAs, one barrier per K-tile.  The block id is mapped XCD-aware (see the kernel): the row blocks that
-// share a weight panel run on ONE XCD, so the panel is fetched from HBM once and re-read from that XCD's L2.
+// (weights) straight from the packed tiles to a PB-deep register ring per wave (each wave owns NTW adjacent 16-column
+// tiles: NTW = 2 is exactly one gate/up pair or one RoPE tile pair), one barrier per K-tile.  The block id is mapped
+// XCD-aware (see the kernel): the row blocks that share a weight panel run on ONE XCD, so the panel is fetched from
+// HBM once and re-read from that XCD's L2.  The host picks (NTW, MT, PB, NW) per projection and prompt length
+// (layerskip_hip.hip, "Prefill tile shapes"); every shape walks K in the same order, so outputs are bit-identical.
+// __launch_bounds__(threads, 2): without the min-waves bound hipcc budgets a 4-wave workgroup 512 registers per wave,
+// parks half of the weight ring in AGPRs and shuffles it back and forth (84 v_accvgpr moves per 128 MFMAs); with it
+// the same code takes 164-204 VGPRs, no AGPRs, two or three waves per SIMD.
 // Epilogues are the ones of lsk_gemm.h (bf16 rounding points of the HF modules).
 // Only prompt rows that are NOT decision rows go through here (their logits are never used), so the
 // different accumulation order never reaches an argmax; it only fills KV pages / exit hiddens.
