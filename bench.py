@@ -137,13 +137,20 @@ def main():
         out = pipeline_bench(args, cfg, E, S, rank, world, dev, backend)
         torch.cuda.empty_cache()
     if mode in ("replica", "pp+replica"):
-        rep = replica_bench(args, cfg, E, S, rank, world, dev, backend, full=(out is None))
+        rep = replica_bench(args, cfg, E, S, rank, world, dev, backend, full=True)
         if out is None:
             out = rep
         elif rank == 0:
             out["replicas"] = {"value": rep["value"], "unit": "tokens/s", "ms_per_step": rep["ms_per_step"],
                                "acceptance_rate": rep["acceptance_rate"],
+                               "path_roofline": rep.get("path_roofline"),
                                "note": f"{world} independent engines, one per GPU, each on its own prompts (weak scaling)"}
+            # the per-kernel evidence of the replica leg (rank 0's engine): every pipeline stage runs these same kernels
+            for key in ("roofline", "kernels", "kernels_note"):
+                if key in rep:
+                    out[key] = rep[key]
+            if "roofline" in out:
+                out["roofline"]["measured_in"] = "replica leg, rank 0 (same kernels as the pipeline stages)"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -289,7 +296,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         out["path_roofline"] = {"algorithmic_bytes_per_generation": total_b // max(1, len(step_traces)),
                                 "floor_tokens_per_s_at_8TBs": round(produced / floor_s, 1),
                                 "frac_of_floor": round((value / world) / (produced / floor_s), 4)}
-    if spec and not args.no_sampled:
+    if spec and not args.no_sampled and world == 1:
         out["sampled"] = sampled_leg(args, cfg, model, E, S, eos, value / world)
     if not args.no_cpu_baseline and world == 1:        # reported on rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args, cfg, model, E, S, strategy, eos)
@@ -350,6 +357,14 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev, backend):
         tokens = sum(len(r.predicted_tokens) for r in results)
         acc = [r.acceptance_rate for r in results if r.acceptance_rate is not None]
         elapsed = float(t.item())
+        total_b = 0
+        for r in results:                                   # decode-bandwidth floor from the run's own (T_d, n) traces
+            trace, c, pl = [], 0, args.prompt_len
+            for (td, n) in r.steps:
+                trace.append((c, pl, td, n))
+                c, pl = c + pl + n, 1
+            total_b += step_bytes(cfg, E, args.prompt_len, trace)
+        floor_tps = tokens / (total_b / (HBM_PEAK_GBS * 1e9)) if total_b else None
         out = {
             "metric": "decoded tokens/sec (self-speculative, greedy)", "value": round(tokens / elapsed, 2), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / max(1, args.steps), 3),
@@ -359,6 +374,11 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev, backend):
                                    f"{args.max_steps} new tokens, batch 1, greedy, random-init weights (late damping {args.late_damping})",
                        "strategy": "self_speculative", "parallelism": f"pp{world}: layer ranges {part}, RCCL point-to-point"},
             "pipeline": getattr(dec, "stats", lambda: {})(),
+            "path_roofline": None if not floor_tps else {
+                "algorithmic_bytes_per_generation": total_b // max(1, len(results)),
+                "floor_tokens_per_s_at_8TBs": round(floor_tps, 1), "frac_of_floor": round(tokens / elapsed / floor_tps, 4),
+                "note": "one sequence is a serial draft -> verify chain: the stages stream their layers one after the other, so the floor "
+                        "is ONE GPU's HBM bandwidth (8 TB/s), not N times it"},
         }
     dec.close() if hasattr(dec, "close") else None
     del dec, engine, model
