@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, ".")
 from layerskip_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load(os.environ["LSK_LIB"]) if os.environ.get("LSK_LIB") else _lib.load()   # LSK_LIB: a variant build (kernel experiments)
 dev = torch.device("cuda:0")
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 
