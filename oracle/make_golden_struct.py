@@ -68,6 +68,9 @@ CASES = {
     "full7b": StructCase("llama2-7B", seed=0, prompt_len=64, max_steps=48),
     # BASELINE config #3 at FULL size: llama3-8B, GQA 32/8, V = 128 256, theta = 5e5, exit_layer 8, 6 speculations
     "full8b": StructCase("llama3-8B", seed=0, prompt_len=64, max_steps=48),
+    # BASELINE config #1 at FULL size: llama3.2-1B (16 layers, d = 64, 32/8 GQA, tied embeddings, llama3 RoPE scaling, V = 128 256),
+    # exit_layer 4, 4 speculations; the reference's own CPU-runnable case
+    "full1b": StructCase("llama3.2-1B", seed=0, prompt_len=64, max_steps=48),
     "tiny_gqa_eos": StructCase("tiny-gqa", seed=0, prompt_len=37, max_steps=48, eos_from="tiny_gqa", eos_index=9),
     "tiny_mha_eos": StructCase("tiny-mha", seed=2, prompt_len=24, max_steps=48, eos_from="tiny_mha", eos_index=5),
 }
