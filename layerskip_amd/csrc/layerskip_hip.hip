@@ -526,9 +526,17 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
         if (p.M == 1) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
         else if (p.M <= 8) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 8>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
         else hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 16>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
+#ifdef LSK_EXPERIMENT_ANY_ORDER
+    // variant builds only (with the kernel body knocked out): dispatches WITHOUT the barrier bit, to see how much of the
+    // dependent-launch floor is the barrier + cache maintenance.  Results are meaningless: nothing orders the launches any more.
+    } else if (p.M == 1) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, p);
+    else if (p.M <= 8) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 8>), dim3(grid), dim3(LSK_THREADS), lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, p);
+    else hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 16>), dim3(grid), dim3(LSK_THREADS), lds, st, nullptr, nullptr, hipExtAnyOrderLaunch, p);
+#else
     } else if (p.M == 1) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 1>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     else if (p.M <= 8) hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 8>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
     else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, 16>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+#endif
     HIP_OK(hipGetLastError());
     if (grid_out) *grid_out = grid;
     return 0;
