@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_uint64, c_vo
 LSK_MAX_ROWS = 16
 LSK_MAX_SPEC = 15
 LSK_MAX_EOS = 8
-LSK_ABI_VERSION = 1
+LSK_ABI_VERSION = 2
 LSK_OPT_BIG_THRESHOLD = 1
 LSK_OPT_TARGET_WGS = 2
 LSK_OPT_FUSED_ATTN = 3
@@ -86,22 +86,8 @@ PROTOTYPES = {
                                             c_float, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_size_t, POINTER(c_int32),
                                             POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                             POINTER(c_int32), c_void_p]),
-    "lsk_test_accept_sampled": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32,
-                                          c_uint64, c_uint64, c_void_p, c_void_p]),
     "lsk_read_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "lsk_write_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
-    "lsk_test_gemm": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_int32, c_void_p]),
-    "lsk_test_accept": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
-    "lsk_test_qkv": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_float, c_int32, c_int32, c_int32, c_void_p, c_void_p,
-                               c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "lsk_test_swiglu": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p]),
-    "lsk_test_resid": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
-    "lsk_test_head_scratch_bytes": (c_int32, [c_int32, POINTER(c_size_t)]),
-    "lsk_test_head": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_int32,
-                                c_void_p, c_void_p]),
-    "lsk_test_attention_scratch_bytes": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_size_t)]),
-    "lsk_test_attention": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
-                                     c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int32, c_void_p]),
     "lsk_time_gateup": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), c_void_p]),
     "lsk_engine_get_host_stats": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_int64)]),
     "lsk_engine_set_profile": (c_int32, [c_void_p, c_int32]),

@@ -12,7 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liblayerskip_hip.so")              # bf16: the BASELINE configs
 LIB_F16 = os.path.join(CSRC, "liblayerskip_hip_f16.so")      # fp16: same sources, -DLSK_ELEM_F16 (generate.py:63's dtype)
-SOURCES = ["layerskip_hip.hip"]
+# test infrastructure: single kernels on caller-owned buffers (include/layerskip_hip_test.h); never loaded by the package
+LIB_TEST = os.path.join(CSRC, "liblayerskip_hip_test.so")
+LIB_TEST_F16 = os.path.join(CSRC, "liblayerskip_hip_test_f16.so")
+SOURCES = ["lsk_engine.hip", "lsk_generate.hip"]             # the product library: two translation units
+TEST_SOURCES = ["lsk_test_exports.hip"]
 
 
 def _inputs():
@@ -29,10 +33,10 @@ def _stale(lib: str) -> bool:
     return any(os.path.getmtime(f) > t for f in _inputs())
 
 
-def _compile(lib: str, defines, verbose: bool) -> None:
+def _compile(lib: str, defines, verbose: bool, sources=None) -> None:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function"] + list(defines) + ["-o", lib] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function"] + list(defines) + ["-o", lib] + [os.path.join(CSRC, s) for s in (sources or SOURCES)]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
@@ -44,10 +48,17 @@ def _compile(lib: str, defines, verbose: bool) -> None:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Builds both libraries in-tree (when stale); returns the bf16 one."""
-    for lib, defines in ((LIB, []), (LIB_F16, ["-DLSK_ELEM_F16"])):
-        if force or _stale(lib):
-            _compile(lib, defines, verbose)
+    """Builds the product libraries (bf16, fp16) and the test libraries in-tree (when stale); returns the bf16 product one."""
+    jobs = ((LIB, [], SOURCES), (LIB_F16, ["-DLSK_ELEM_F16"], SOURCES),
+            (LIB_TEST, [], TEST_SOURCES), (LIB_TEST_F16, ["-DLSK_ELEM_F16"], TEST_SOURCES))
+    stale = [j for j in jobs if force or _stale(j[0])]
+    if len(stale) > 1:
+        from concurrent.futures import ThreadPoolExecutor      # hipcc is a subprocess: the four builds run side by side
+        with ThreadPoolExecutor(max_workers=len(stale)) as pool:
+            list(pool.map(lambda j: _compile(j[0], j[1], verbose, j[2]), stale))
+    else:
+        for lib, defines, sources in stale:
+            _compile(lib, defines, verbose, sources)
     return LIB
 
 

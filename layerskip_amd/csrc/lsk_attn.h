@@ -33,7 +33,6 @@
 #define LSK_ATTN_NEG (-1.0e30f)
 #define LSK_ATTN_THREADS 256
 #define LSK_ATTN_WAVES 4
-#define LSK_ATTN_PAGE 128          // keys per workgroup == KV page size
 
 struct AttnSplitParams {
     const elem_t* q;        // [M][ldq]
@@ -94,8 +93,16 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
     const int key0 = page_l * LSK_ATTN_PAGE;
     const bool fused = p.counters != nullptr;
     // ---- every load of this wave up front ----
+    // the two device scalars first, in ONE scalar-load clause (pinned: hipcc otherwise sinks the block-table read below the
+    // early return, which put a third dependent scalar round trip in front of the K / V requests of a ~5 us kernel)
+    // (the kernel arguments the address arithmetic needs ride along, instead of being read lazily in a clause of their own;
+    // nothing with side effects may stand BEFORE the two reads: hipcc then no longer proves them clobber-free and turns the
+    // scalar loads into vector loads)
     const int page = p.block_table[page_l];
-    const int base_pos = *p.kv_len + p.pos_off;
+    const int kv_now = *p.kv_len;
+    asm volatile("" : : "s"(page), "s"(kv_now), "s"(p.q), "s"(p.ldq), "s"(p.kpool), "s"(p.vpool), "s"(p.n_kv), "s"(p.group), "s"(p.M),
+                 "s"(p.pos_off), "s"(p.heads_per_wg), "s"(p.inv_m), "s"(p.counters));
+    const int base_pos = kv_now + p.pos_off;
     const int qi = min(c16, n_rows - 1);
     const int qh = (qi * p.inv_m) >> 8;
     const elem_t* qp = p.q + (size_t)(qi - qh * M) * p.ldq + (size_t)(head0 + qh) * HD + g * 8;

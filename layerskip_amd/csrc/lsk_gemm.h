@@ -45,6 +45,19 @@ __device__ __forceinline__ UnitInfo lsk_unit_info(int u, int units, int ntl, int
 }
 
 #define LSK_OOB_OFFSET 0xF0000000u
+#ifndef LSK_RING_EARLY
+#define LSK_RING_EARLY 1
+#endif
+#ifndef LSK_HEAD_DPP
+#define LSK_HEAD_DPP 1
+#endif
+
+template <int ROT>
+__device__ __forceinline__ void lsk_row16_argmax_step(float& v, int& idx) {
+    const float ov = lsk_dpp<LSK_ROW_ROR(ROT)>(v);
+    const int oi = lsk_dpp<LSK_ROW_ROR(ROT)>(idx);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
 
 // LDS carve (bytes)
 #define LSK_LDS_SLAB 0          // [2][8][256] f32 = 16384
@@ -114,7 +127,16 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     const int ntl = min(p.tiles_per_wg, p.n_tiles - tile0);
     const int units = nchunks * ntl;
     const int xstride = lsk_gemm_xstride(p.K);
-    const int M = p.M;
+    // Every kernel argument the prologue needs is read in ONE scalar-load clause: hipcc otherwise fetches the argument block
+    // lazily, a few fields at a time where they are first used -- three dependent kernarg round trips stood in front of the
+    // activation loads and the weight ring of every projection launch.  (No `volatile`: an asm with side effects in front of
+    // `*p.kv_len` below would make hipcc demote that scalar load to a vector load; the tie to M keeps the statement alive.)
+    int M = p.M;
+    asm("" : "+s"(M) : "s"(p.x), "s"(p.ldx), "s"(p.K), "s"(p.wp), "s"(p.wp_bytes), "s"(p.N), "s"(p.n_tiles), "s"(p.tiles_per_wg));
+    if (PRO == PRO_RMS) asm("" : "+s"(M) : "s"(p.norm_w), "s"(p.eps));
+    if (EPI == EPI_RESID) asm("" : "+s"(M) : "s"(p.h), "s"(p.ldh));
+    if (EPI == EPI_QKV) asm("" : "+s"(M) : "s"(p.kv_len), "s"(p.pos_off), "s"(p.rope_cos), "s"(p.rope_sin), "s"(p.block_table), "s"(p.page_size),
+                            "s"(p.n_heads), "s"(p.n_kv), "s"(p.head_dim));
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
 
@@ -125,18 +147,21 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     const int rg = lane >> 4;
     const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : ntl;
     const bool is_owner = w < n_owned;
-    float pre_a[4] = {0.f, 0.f, 0.f, 0.f};      // RESID: residual values | QKV: cos
-    float pre_b[4] = {0.f, 0.f, 0.f, 0.f};      // QKV: sin
+    // The values are kept RAW (model dtype) and every lane loads from a clamped, always-valid address: a conversion or a
+    // lane predicate at the load makes hipcc wait for each load where it stands (branch around it + s_waitcnt vmcnt(0)), which
+    // put 1-4 SERIAL L2 round trips in front of the owner waves' activation loads and weight ring -- the whole workgroup
+    // then waited for them at the first barrier (ISA of the round-2 build: 4 waited global_load_ushort at the top of the
+    // o_proj / down kernels of a verify pass, 4 waited cos/sin pairs + 4 block-table loads at the top of q/k/v).
+    elem_t pre_a[4], pre_b[4];                  // RESID: residual values (pre_a) | QKV: cos, sin
     int pre_pg[4] = {0, 0, 0, 0};               // QKV: KV page of each row's position
     int base_pos = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pre_a[i] = (elem_t)0.0f; pre_b[i] = (elem_t)0.0f; }
     if (EPI == EPI_RESID) {
         if (is_owner) {
-            const int n = (tile0 + w) * 16 + c16;
+            const int n = min((tile0 + w) * 16 + c16, p.N - 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = rg * 4 + i;
-                if (row < M && n < p.N) pre_a[i] = e2f(p.h[(size_t)row * p.ldh + n]);
-            }
+            for (int i = 0; i < 4; ++i) pre_a[i] = p.h[(size_t)min(rg * 4 + i, M - 1) * p.ldh + n];
         }
     } else if (EPI == EPI_QKV) {
         base_pos = *p.kv_len + p.pos_off;
@@ -150,14 +175,17 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
             const int tt = TT - (TT / tph) * tph;
             const int j = tt * 8 + (c16 & 7);
+            if (kind != 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int pos = base_pos + min(rg * 4 + i, M - 1);
-                if (kind != 2) {
-                    pre_a[i] = e2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
-                    pre_b[i] = e2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
+                for (int i = 0; i < 4; ++i) {
+                    const int pos = base_pos + min(rg * 4 + i, M - 1);
+                    pre_a[i] = p.rope_cos[(size_t)pos * (hd >> 1) + j];
+                    pre_b[i] = p.rope_sin[(size_t)pos * (hd >> 1) + j];
                 }
-                if (kind != 0) pre_pg[i] = p.block_table[pos / p.page_size];
+            }
+            if (kind != 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pre_pg[i] = p.block_table[(base_pos + min(rg * 4 + i, M - 1)) / p.page_size];
             }
         }
     }
@@ -165,7 +193,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     // ---- activations next (they must not queue behind the weight ring), then fill the ring ----
     UnitInfo cur = lsk_unit_info(0, units, ntl, ksteps, tile0, w, lane);
     elem8 xr[MB];
-    elem8 nw;
+    elem8 nw = {};
     float ss[MB];
     float sv[MB];                 // per-row 1/rms (PRO_RMS), wave-uniform
     u32x4 ring[LSK_SPW];
@@ -173,7 +201,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
         for (int i = 0; i < MB; ++i) ss[i] = 0.f;
         // RMSNorm statistics need whole rows: walk the K-chunks last-to-first so chunk 0 stays in xr
-        for (int c = nchunks - 1; c >= 0; --c) {
+        for (int c = nchunks - 1; c >= LSK_RING_EARLY; --c) {
             const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
             lsk_load_chunk<PRO, MB>(p, c, steps_c, tid, xr, nw);
             if (tid * 8 < steps_c * 32) {
@@ -183,6 +211,10 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                     for (int j = 0; j < 8; ++j) { const float f = e2f(xr[i][j]); ss[i] = fmaf(f, f, ss[i]); }
             }
         }
+        // chunk 0 is only REQUESTED here: the weight ring is queued right behind it, so the first HBM round trip of the
+        // stream overlaps the round trip of the rows instead of following it (a wave's loads retire in order: the rows
+        // arrive first, the statistics below run under the ring's flight time)
+        if (LSK_RING_EARLY) lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
     } else {
         lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
     }
@@ -192,6 +224,12 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
         ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
     }
     if (PRO == PRO_RMS) {
+        if (LSK_RING_EARLY && tid * 8 < cur.steps_c * 32) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = e2f(xr[i][j]); ss[i] = fmaf(f, f, ss[i]); }
+        }
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const float t = wave_sum(ss[i]);
@@ -282,7 +320,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
                 if (row < M && n < p.N) {
-                    p.h[(size_t)row * p.ldh + n] = f2e(pre_a[i] + rnd_e(own0[i]));   // residual + Linear(...) in model dtype
+                    p.h[(size_t)row * p.ldh + n] = f2e(e2f(pre_a[i]) + rnd_e(own0[i]));   // residual + Linear(...) in model dtype
                 }
             }
         }
@@ -320,8 +358,8 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                 if (kind != 2) {
                     const float partner = row_xor8(v);
                     const int j = tt * 8 + (c16 & 7);
-                    const float cs = pre_a[i];
-                    const float sn = pre_b[i];
+                    const float cs = e2f(pre_a[i]);
+                    const float sn = e2f(pre_b[i]);
                     const float a = rnd_e(v * cs);                               // q * cos
                     const float b = rnd_e((c16 < 8 ? -partner : partner) * sn);  // rotate_half(q) * sin
                     v = rnd_e(a + b);
@@ -355,12 +393,24 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                 int idx = n;
                 if (n >= p.N) { v = -INFINITY; idx = 0x7fffffff; }
                 // argmax over the tile's 16 columns, first (lowest) index wins ties like torch.argmax
+#if LSK_HEAD_DPP
+                // row rotations (DPP, a few cycles each) instead of ds_bpermute round trips: the (value, index) maximum with
+                // the lowest-index tie-break is associative and commutative, so after rotations by 8, 4, 2, 1 every lane of
+                // the 16-lane row holds the row's result; rows >= M of a short pass are skipped (i >= M: no lane group has one)
+                if (i < M) {
+                    lsk_row16_argmax_step<8>(v, idx);
+                    lsk_row16_argmax_step<4>(v, idx);
+                    lsk_row16_argmax_step<2>(v, idx);
+                    lsk_row16_argmax_step<1>(v, idx);
+                }
+#else
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) {
                     const float ov = __shfl_xor(v, o, 64);
                     const int oi = __shfl_xor(idx, o, 64);
                     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
                 }
+#endif
                 if (c16 == 0) { best_v[w * 16 + row] = v; best_i[w * 16 + row] = idx; }
             }
         }

@@ -8,7 +8,7 @@
 // tiles: NTW = 2 is exactly one gate/up pair or one RoPE tile pair), one barrier per K-tile.  The block id is mapped
 // XCD-aware (see the kernel): the row blocks that share a weight panel run on ONE XCD, so the panel is fetched from
 // HBM once and re-read from that XCD's L2.  The host picks (NTW, MT, PB, NW) per projection and prompt length
-// (layerskip_hip.hip, "Prefill tile shapes"); every shape walks K in the same order, so outputs are bit-identical.
+// (lsk_engine.hip, "Prefill tile shapes"); every shape walks K in the same order, so outputs are bit-identical.
 // __launch_bounds__(threads, 2): without the min-waves bound hipcc budgets a 4-wave workgroup 512 registers per wave,
 // parks half of the weight ring in AGPRs and shuffles it back and forth (84 v_accvgpr moves per 128 MFMAs); with it
 // the same code takes 164-204 VGPRs, no AGPRs, two or three waves per SIMD.

@@ -1,0 +1,85 @@
+// Launch wrappers of the kernels both libraries launch (the engine in lsk_engine.hip, the isolated kernel tests in
+// lsk_test_exports.hip): the skinny projection kernel with its workgroup / template selection, the prefill attention kernel.
+// Including this header instantiates those kernels in the including translation unit.
+#pragma once
+#include "lsk_host.h"
+#include "lsk_attn.h"
+#include "lsk_gemm.h"
+
+static const size_t kMaxGemmLds = 160 * 1024;
+#ifndef LSK_MB_MID
+#define LSK_MB_MID 8              // rows of the middle template of the skinny projection kernel (1 | LSK_MB_MID | 16)
+#endif
+
+template <int PRO, int EPI>
+static int set_gemm_attr() {
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    return 0;
+}
+
+// hipFuncSetAttribute is per device: done once per device of this process, under a lock (engines may be created from
+// several host threads; the supported deployment is one process per GPU, but nothing here relies on it).
+static int init_kernel_attrs() {
+    static std::mutex mu;
+    static unsigned long long done_mask = 0;
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && (done_mask >> dev) & 1ull) return 0;
+    LSK_TRY((set_gemm_attr<PRO_PLAIN, EPI_F32>()));
+    LSK_TRY((set_gemm_attr<PRO_RMS, EPI_F32>()));
+    LSK_TRY((set_gemm_attr<PRO_PLAIN, EPI_RESID>()));
+    LSK_TRY((set_gemm_attr<PRO_RMS, EPI_SWIGLU>()));
+    LSK_TRY((set_gemm_attr<PRO_RMS, EPI_QKV>()));
+    LSK_TRY((set_gemm_attr<PRO_RMS, EPI_HEAD>()));
+    if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+    return 0;
+}
+
+static int tiles_per_wg(int n_units, int target_wgs) {   // units = tiles (or gate/up pairs)
+    int t = (n_units + target_wgs - 1) / target_wgs;
+    return t < 1 ? 1 : (t > 8 ? 8 : t);
+}
+
+template <int PRO, int EPI, int MB>
+static void launch_gemm_mb(const GemmParams& p, int grid, size_t lds, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (ev_start != nullptr) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
+    else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+}
+
+template <int PRO, int EPI>
+static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_out = nullptr, hipEvent_t ev_start = nullptr,
+                       hipEvent_t ev_stop = nullptr) {
+    const int unit = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int n_units = p.n_tiles / unit;
+    p.tiles_per_wg = tiles_per_wg(n_units, target_wgs) * unit;
+    const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
+    if (lds > kMaxGemmLds) return lsk_fail("gemm LDS %zu exceeds %zu", lds, kMaxGemmLds);
+    // 32-bit buffer offsets; the out-of-range sentinel of ragged ring slots must stay beyond the descriptor's range
+    if ((size_t)p.n_tiles * 16 * (size_t)p.K * 2 >= (size_t)LSK_OOB_OFFSET) return lsk_fail("packed weight of %d x %d exceeds the 32-bit buffer range", p.n_tiles * 16, p.K);
+    // profiling (ev_start != nullptr): the events are bound to THIS dispatch's own begin / end timestamps (what rocprofv3 reports)
+    if (p.M == 1) launch_gemm_mb<PRO, EPI, 1>(p, grid, lds, st, ev_start, ev_stop);
+    else if (p.M <= LSK_MB_MID) launch_gemm_mb<PRO, EPI, LSK_MB_MID>(p, grid, lds, st, ev_start, ev_stop);
+    else launch_gemm_mb<PRO, EPI, 16>(p, grid, lds, st, ev_start, ev_stop);
+    HIP_OK(hipGetLastError());
+    if (grid_out) *grid_out = grid;
+    return 0;
+}
+
+#ifndef LSK_PF_RT
+#define LSK_PF_RT 2               // 16-row query tiles per workgroup of the prefill attention kernel (lsk_attn.h)
+#endif
+#ifndef LSK_PF_PREFETCH
+#define LSK_PF_PREFETCH 0         // fragments requested one 32-key sub-block ahead: 0 none, 1 K, 2 K and V^T (measured: no gain, fewer waves)
+#endif
+static int launch_attn_prefill(const AttnPrefillParams& ap, int n_heads, int head_dim, int rows, hipStream_t st) {
+    const dim3 grid(n_heads, (rows + 16 * LSK_PF_RT - 1) / (16 * LSK_PF_RT)), block(LSK_ATTN_THREADS);
+    if (head_dim == 128) hipLaunchKernelGGL((lsk_attn_prefill_kernel<128, LSK_PF_RT, LSK_PF_PREFETCH>), grid, block, 0, st, ap);
+    else hipLaunchKernelGGL((lsk_attn_prefill_kernel<64, LSK_PF_RT, LSK_PF_PREFETCH>), grid, block, 0, st, ap);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+

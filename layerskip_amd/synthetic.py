@@ -83,6 +83,12 @@ SHAPES: Dict[str, dict] = {
                                        high_freq_factor=4.0,
                                        original_max_position_embeddings=8192),
                      max_position_embeddings=131072, exit_layer=2, num_speculations=4),
+    # llama2-70B geometry on 4 layers: H = 8192 (two K-chunks), I = 28672 (seven K-chunks in down_proj), 64 : 8 GQA, and the
+    # config's 12 speculations (a 13-row verify block: the 16-row template, one query head per attention workgroup)
+    "slice-70B": dict(num_hidden_layers=4, hidden_size=8192, intermediate_size=28672,
+                      num_attention_heads=64, num_key_value_heads=8, head_dim=128,
+                      vocab_size=32000, rope_theta=10000.0, max_position_embeddings=4096,
+                      exit_layer=2, num_speculations=12),
     # Wide enough that K > 4096 (two K-chunks in every projection) like 70B / 13B.
     "small-wide": dict(num_hidden_layers=4, hidden_size=5120, intermediate_size=6144,
                        num_attention_heads=40, num_key_value_heads=8, head_dim=128,

@@ -71,6 +71,13 @@ CASES = {
     # BASELINE config #1 at FULL size: llama3.2-1B (16 layers, d = 64, 32/8 GQA, tied embeddings, llama3 RoPE scaling, V = 128 256),
     # exit_layer 4, 4 speculations; the reference's own CPU-runnable case
     "full1b": StructCase("llama3.2-1B", seed=0, prompt_len=64, max_steps=48),
+    # the BENCHMARKED workload (bench.py: 512-token prompt) at full size: 511-row MFMA prefill, the context crosses 6 KV pages,
+    # > 100 pipelined speculation steps
+    "full7b_512": StructCase("llama2-7B", seed=0, prompt_len=512, max_steps=256),
+    # BASELINE config #5's geometry (llama2-70B: H = 8192, I = 28672, 64 : 8 GQA) with its 12 speculations: 13-row verify blocks
+    "slice70b": StructCase("slice-70B", seed=0, prompt_len=40, max_steps=40, fp32=False),
+    # BASELINE config #4 at FULL size: llama2-13B (40 layers, H = 5120), exit_layer 10, 8 speculations (9-row verify blocks)
+    "full13b": StructCase("llama2-13B", seed=0, prompt_len=64, max_steps=48, fp32=False),
     "tiny_gqa_eos": StructCase("tiny-gqa", seed=0, prompt_len=37, max_steps=48, eos_from="tiny_gqa", eos_index=9),
     "tiny_mha_eos": StructCase("tiny-mha", seed=2, prompt_len=24, max_steps=48, eos_from="tiny_mha", eos_index=5),
 }

@@ -133,7 +133,7 @@ class CpuStageBackend:
     def write_rows(self, buffer, row_base, rows):
         self.buf[buffer][row_base:row_base + rows.shape[0]] = rows.float()
 
-    # ---- the orchestration of lsk_spec_step_sampled (layerskip_hip.hip) with the oracle's model of the two kernels
+    # ---- the orchestration of lsk_spec_step_sampled (lsk_generate.hip) with the oracle's model of the two kernels
     def spec_step_sampled(self, input_ids, num_speculations, exit_layer, eos_token_ids, temperature, top_k, top_p, seed, offset):
         import numpy as np
         from layerskip_amd.engine import StepResult

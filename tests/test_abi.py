@@ -6,8 +6,8 @@ import re
 from conftest import ROOT
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "layerskip_hip.h")).read()
+def _header_symbols(header="layerskip_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(lsk_[a-z0-9_]+)\s*\(", text)))
 
@@ -29,6 +29,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib16, name), name
     assert lib16.lsk_elem_dtype() == 1 and lib16.lsk_abi_version() == _lib.LSK_ABI_VERSION
     assert lib16 is not lib
+
+
+def test_test_library_exports_its_header_and_the_product_library_holds_no_test_code():
+    """liblayerskip_hip_test.so = include/layerskip_hip_test.h; nothing named lsk_test_* lives in the product library, and the
+    package's binding does not know the test library."""
+    import lsk_test_lib
+    from layerskip_amd import _lib
+    declared = _header_symbols("layerskip_hip_test.h")
+    assert declared and all(n.startswith("lsk_test_") for n in declared)
+    assert sorted(lsk_test_lib.PROTOTYPES) == declared
+    for dtype, code in (("bf16", 0), ("fp16", 1)):
+        tlib = lsk_test_lib.load(dtype)
+        for name in declared:
+            assert hasattr(tlib, name), name
+        assert tlib.lsk_test_abi_version() == _lib.LSK_ABI_VERSION and tlib.lsk_test_elem_dtype() == code
+        assert not hasattr(tlib, "lsk_engine_create")
+    lib = _lib.load()
+    for name in declared:
+        assert not hasattr(lib, name), f"{name} is exported by the product library"
+    assert not any(n.startswith("lsk_test_") for n in _lib.PROTOTYPES)
+    src = open(os.path.join(ROOT, "layerskip_amd", "_lib.py")).read() + open(os.path.join(ROOT, "layerskip_amd", "engine.py")).read()
+    assert "hip_test" not in src
 
 
 def test_size_queries_need_no_gpu():

@@ -12,6 +12,12 @@ def _lib():
     return _lib.load(), _lib
 
 
+def _tlib():
+    """liblayerskip_hip_test.so (include/layerskip_hip_test.h): the engine's kernels on caller-owned buffers."""
+    import lsk_test_lib
+    return lsk_test_lib.load(), lsk_test_lib
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -30,7 +36,7 @@ def _gemm(x, wp, n, norm_w=None, eps=1e-5, target_wgs=0):
     lib, L = _lib()
     m, k = x.shape
     y = torch.full((m, n), float("nan"), dtype=torch.float32, device=x.device)
-    L.check(lib.lsk_test_gemm(x.data_ptr(), m, k, wp.data_ptr(), n, None if norm_w is None else norm_w.data_ptr(),
+    _tlib()[1].check(_tlib()[0].lsk_test_gemm(x.data_ptr(), m, k, wp.data_ptr(), n, None if norm_w is None else norm_w.data_ptr(),
                               eps, y.data_ptr(), target_wgs, _stream()))
     torch.cuda.synchronize()
     return y
@@ -108,7 +114,7 @@ def test_accept_kernel(gpu_device, drafts, verified, eos, expect):
     v = torch.tensor(verified, dtype=torch.int32, device=gpu_device)
     e = torch.tensor(eos + [0], dtype=torch.int32, device=gpu_device)
     res = torch.full((64,), -1, dtype=torch.int32, device=gpu_device)
-    L.check(lib.lsk_test_accept(d.data_ptr(), v.data_ptr(), len(drafts), e.data_ptr(), len(eos), res.data_ptr(), _stream()))
+    _tlib()[1].check(_tlib()[0].lsk_test_accept(d.data_ptr(), v.data_ptr(), len(drafts), e.data_ptr(), len(eos), res.data_ptr(), _stream()))
     torch.cuda.synchronize()
     r = res.tolist()
     n, td = expect

@@ -1,5 +1,5 @@
 """Isolated, BIT-EXACT checks of the fused epilogues and tight checks of the attention kernels, through the C-ABI
-(`lsk_test_*`, include/layerskip_hip.h), against plain torch statements of the HF ops they replace.
+(`lsk_test_*`, include/layerskip_hip_test.h, liblayerskip_hip_test.so), against plain torch statements of the HF ops they replace.
 
 The projections use one-hot ("permutation") weights and activations whose RMS statistics are exact, so the GEMM and
 the RMSNorm are exact and the epilogue under test must reproduce torch's bf16 arithmetic bit for bit:
@@ -26,6 +26,12 @@ PAGE = 128
 def _lib():
     from layerskip_amd import _lib
     return _lib.load(), _lib
+
+
+def _tlib():
+    """liblayerskip_hip_test.so (include/layerskip_hip_test.h): the engine's kernels on caller-owned buffers."""
+    import lsk_test_lib
+    return lsk_test_lib.load(), lsk_test_lib
 
 
 def _stream():
@@ -134,7 +140,7 @@ def test_qkv_rope_kv_append_bit_exact(gpu_device, shape_name, n_heads, n_kv, hd,
     cos_h = cos_t[:, : hd // 2].contiguous().to(dev)
     sin_h = sin_t[:, : hd // 2].contiguous().to(dev)
     xd, gd, td = x.to(dev), gain.to(dev), table.to(dev)
-    L.check(lib.lsk_test_qkv(xd.data_ptr(), m, H, wp.data_ptr(), gd.data_ptr(), eps, n_heads, n_kv, hd, cos_h.data_ptr(),
+    _tlib()[1].check(_tlib()[0].lsk_test_qkv(xd.data_ptr(), m, H, wp.data_ptr(), gd.data_ptr(), eps, n_heads, n_kv, hd, cos_h.data_ptr(),
                              sin_h.data_ptr(), kvl.data_ptr(), 0, td.data_ptr(), q_out.data_ptr(), kpool.data_ptr(),
                              vpool.data_ptr(), _stream()))
     torch.cuda.synchronize()
@@ -170,7 +176,7 @@ def test_swiglu_epilogue_bit_exact(gpu_device, m, H, I):
     _pack_into(wp, wu.to(dev), 1, 2, 0)
     act = torch.zeros(m, I, dtype=BF, device=dev)
     xd, gd = x.to(dev), gain.to(dev)
-    L.check(lib.lsk_test_swiglu(xd.data_ptr(), m, H, wp.data_ptr(), gd.data_ptr(), eps, I, act.data_ptr(), _stream()))
+    _tlib()[1].check(_tlib()[0].lsk_test_swiglu(xd.data_ptr(), m, H, wp.data_ptr(), gd.data_ptr(), eps, I, act.data_ptr(), _stream()))
     torch.cuda.synchronize()
     assert torch.equal(act.cpu(), want)
     assert gate.unique().numel() > 10                                # the check is not vacuous
@@ -188,7 +194,7 @@ def test_residual_epilogue_bit_exact(gpu_device, m, K, N):
     wp = _packed(N, K, dev)
     _pack_into(wp, w.to(dev))
     hd_, xd = h.to(dev).clone(), x.to(dev)
-    L.check(lib.lsk_test_resid(xd.data_ptr(), m, K, wp.data_ptr(), N, hd_.data_ptr(), _stream()))
+    _tlib()[1].check(_tlib()[0].lsk_test_resid(xd.data_ptr(), m, K, wp.data_ptr(), N, hd_.data_ptr(), _stream()))
     torch.cuda.synchronize()
     assert torch.equal(hd_.cpu(), want)
 
@@ -238,13 +244,13 @@ def test_lm_head_exact_ties_resolve_to_lowest_index(gpu_device, m, V, target_wgs
     wp = _packed(V, H, dev)
     _pack_into(wp, w.to(dev))
     nb = ctypes.c_size_t(0)
-    L.check(lib.lsk_test_head_scratch_bytes(V, ctypes.byref(nb)))
+    _tlib()[1].check(_tlib()[0].lsk_test_head_scratch_bytes(V, ctypes.byref(nb)))
     scratch = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
     ld = (V + 3) // 4 * 4
     logits = torch.zeros(m, ld, dtype=torch.float32, device=dev)
     toks = torch.full((m,), -1, dtype=torch.int32, device=dev)
     xd, gd = x.to(dev), gain.to(dev)
-    L.check(lib.lsk_test_head(xd.data_ptr(), m, H, wp.data_ptr(), gd.data_ptr(), eps, V, target_wgs, scratch.data_ptr(),
+    _tlib()[1].check(_tlib()[0].lsk_test_head(xd.data_ptr(), m, H, wp.data_ptr(), gd.data_ptr(), eps, V, target_wgs, scratch.data_ptr(),
                               logits.data_ptr(), ld, toks.data_ptr(), _stream()))
     torch.cuda.synchronize()
     got_logits = logits[:, :V].cpu()
@@ -308,12 +314,12 @@ def test_attention_matches_fp32_softmax(gpu_device, mode, n_heads, n_kv, hd, m, 
     scores = scores.masked_fill(keys > rows, float("-inf"))
     ref = torch.einsum("hmc,chd->mhd", torch.softmax(scores, dim=-1), vd).reshape(m, n_heads * hd)
     nb = ctypes.c_size_t(0)
-    L.check(lib.lsk_test_attention_scratch_bytes(n_heads, hd, n_pages, ctypes.byref(nb)))
+    _tlib()[1].check(_tlib()[0].lsk_test_attention_scratch_bytes(n_heads, hd, n_pages, ctypes.byref(nb)))
     scratch = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
     out = torch.full((m, n_heads * hd), float("nan"), dtype=BF, device=dev)
     kvl = torch.tensor([kv_len], dtype=torch.int32, device=dev)
     qdev, td = q.reshape(m, n_heads * hd).to(dev), table.to(dev)
-    L.check(lib.lsk_test_attention(qdev.data_ptr(), m, n_heads, n_kv, hd, kpool.data_ptr(), vpool.data_ptr(), td.data_ptr(),
+    _tlib()[1].check(_tlib()[0].lsk_test_attention(qdev.data_ptr(), m, n_heads, n_kv, hd, kpool.data_ptr(), vpool.data_ptr(), td.data_ptr(),
                                    n_pages, kvl.data_ptr(), kv_len, 0, scratch.data_ptr(), nb.value, out.data_ptr(), mode,
                                    _stream()))
     torch.cuda.synchronize()

@@ -51,9 +51,9 @@ def test_sample_rows_matches_the_model_draw_for_draw(gpu_device, idx):
 
 
 def test_accept_sampled_kernel_matches_the_model(gpu_device):
-    from layerskip_amd import _lib
+    import lsk_test_lib
     from oracle import sampling_oracle as so
-    lib = _lib.load()
+    lib = lsk_test_lib.load()
     rng = np.random.default_rng(3)
     v, ld = 640, 640
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -70,7 +70,7 @@ def test_accept_sampled_kernel_matches_the_model(gpu_device):
         pd_dev = torch.tensor(np.stack(pd), device=gpu_device)
         pv_dev = torch.tensor(np.stack(pv), device=gpu_device)
         res = torch.zeros(64, dtype=torch.int32, device=gpu_device)
-        _lib.check(lib.lsk_test_accept_sampled(d_dev.data_ptr() + 4, v_dev.data_ptr(), td, e_dev.data_ptr(), len(eos), pd_dev.data_ptr(),
+        lsk_test_lib.check(lib.lsk_test_accept_sampled(d_dev.data_ptr() + 4, v_dev.data_ptr(), td, e_dev.data_ptr(), len(eos), pd_dev.data_ptr(),
                                                pv_dev.data_ptr(), ld, v, 77, trial, res.data_ptr(), st))
         torch.cuda.synchronize()
         r = res.cpu().tolist()

@@ -6,9 +6,13 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import lsk_test_lib  # noqa: E402
 from layerskip_amd import _lib  # noqa: E402
 
-lib = _lib.load(os.environ["LSK_LIB"]) if os.environ.get("LSK_LIB") else _lib.load()   # LSK_LIB: a variant build (kernel experiments)
+lib = _lib.load()
+# LSK_TEST_LIB: a variant build of the TEST library (hipcc -D... layerskip_amd/csrc/lsk_test_exports.hip), for kernel experiments
+tlib = lsk_test_lib.load(path=os.environ["LSK_TEST_LIB"]) if os.environ.get("LSK_TEST_LIB") else lsk_test_lib.load()
 dev = torch.device("cuda:0")
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 
@@ -27,7 +31,7 @@ def run(k, n, m, wgs, with_norm, nbuf=None, iters=60):
     nw = torch.ones(k, device=dev, dtype=torch.bfloat16)
     y = torch.empty(m, n, dtype=torch.float32, device=dev)
     def launch(i):
-        _lib.check(lib.lsk_test_gemm(x.data_ptr(), m, k, bufs[i % nbuf].data_ptr(), n, nw.data_ptr() if with_norm else None,
+        lsk_test_lib.check(tlib.lsk_test_gemm(x.data_ptr(), m, k, bufs[i % nbuf].data_ptr(), n, nw.data_ptr() if with_norm else None,
                                      1e-5, y.data_ptr(), wgs, st()))
     for i in range(nbuf):
         launch(i)

@@ -90,7 +90,9 @@ def main():
             a64 = torch.einsum("hmc,hcd->mhd", torch.softmax(sc, -1), v[0].double().repeat_interleave(g, 0)).reshape(n, -1)
             report("oracle SDPA vs fp64 attention", a2[0], a64.float(), scale_floor=float(a64.pow(2).mean().sqrt()) / 8)
             # engine attention kernel on the oracle's q / k / v
-            lib = _lib.load()
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import lsk_test_lib
+            lib = lsk_test_lib.load()
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             n_pages = (n + 127) // 128 + 1
             kpool = torch.zeros(n_pages, om.n_kv_heads, 128, om.head_dim, dtype=torch.bfloat16)
@@ -101,7 +103,7 @@ def main():
             kpool, vpool = kpool.to(dev), vpool.to(dev)
             table = torch.arange(n_pages, dtype=torch.int32, device=dev)
             nb = ctypes.c_size_t(0)
-            _lib.check(lib.lsk_test_attention_scratch_bytes(om.n_heads, om.head_dim, n_pages, ctypes.byref(nb)))
+            lsk_test_lib.check(lib.lsk_test_attention_scratch_bytes(om.n_heads, om.head_dim, n_pages, ctypes.byref(nb)))
             scratch = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
             qd = qr[0].transpose(0, 1).reshape(n, -1).contiguous().to(dev)
             outs = []
@@ -109,7 +111,7 @@ def main():
                 m = min(16, n - r0)
                 out = torch.zeros(m, om.n_heads * om.head_dim, dtype=torch.bfloat16, device=dev)
                 kvl = torch.tensor([r0], dtype=torch.int32, device=dev)
-                _lib.check(lib.lsk_test_attention(qd[r0:r0 + m].data_ptr(), m, om.n_heads, om.n_kv_heads, om.head_dim, kpool.data_ptr(),
+                lsk_test_lib.check(lib.lsk_test_attention(qd[r0:r0 + m].data_ptr(), m, om.n_heads, om.n_kv_heads, om.head_dim, kpool.data_ptr(),
                                                   vpool.data_ptr(), table.data_ptr(), n_pages, kvl.data_ptr(), r0, 0, scratch.data_ptr(),
                                                   nb.value, out.data_ptr(), 0, st))
                 torch.cuda.synchronize()
