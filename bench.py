@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--late-damping", type=float, default=0.03)
     ap.add_argument("--strategy", default="self_speculative", choices=["self_speculative", "autoregressive"])
     ap.add_argument("--target-wgs", type=int, default=0)
+    ap.add_argument("--pp-balance", default="draft", choices=["draft", "memory"],
+                    help="layer split of the pipeline: 'draft' = rank 0 owns exactly the early layers (default); 'memory' = layers spread "
+                         "evenly by count (llama2-13B on two GPUs: [0,20)+[20,40))")
     ap.add_argument("--parallelism", default="auto", choices=["auto", "replica", "pp"],
                     help="multi-GPU mode.  auto (default): the layer-range pipeline is the headline and the replica "
                          "throughput an extra key; replica / pp: only that one")
@@ -60,6 +63,10 @@ def parse_args():
     ap.add_argument("--gpu-reference", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling: now the default
     ap.add_argument("--gpu-reference-tokens", type=int, default=128)
     ap.add_argument("--no-sampled", action="store_true", help="skip the sample=True throughput leg")
+    ap.add_argument("--no-operating-points", action="store_true",
+                    help="skip the two extra operating points (late damping giving acceptance ~0.5 and ~0.8)")
+    ap.add_argument("--operating-points", default="0.05,0.015",
+                    help="late-damping values of the extra operating points (the headline stays at --late-damping)")
     ap.add_argument("--graph-steps", action="store_true",
                     help="replay steady-state speculation steps from hipGraphs (LSK_OPT_GRAPH_STEPS; default off, DESIGN.md 3.3)")
     return ap.parse_args()
@@ -302,7 +309,50 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         out["cpu_baseline"] = cpu_baseline(args, cfg, model, E, S, strategy, eos)
     if spec and not args.no_gpu_reference and world == 1:
         out["gpu_reference"] = gpu_reference(args, cfg, model, E, S, eos, value / world)
+    if spec and not args.no_operating_points and world == 1 and not big:
+        out["operating_points"] = operating_points(args, cfg, model, E, S, eos, strategy, gen)     # last: it rescales weights in place
     return out
+
+
+def operating_points(args, cfg, model, E, S, eos, strategy, gen):
+    """The headline depends on the acceptance rate, and on random-init weights that is set by ONE knob (the late-layer damping,
+    frozen at --late-damping for the headline).  Two more points of the same workload -- the damped projections rescaled in
+    place, the engine re-packs on its own -- so that kernel quality (fraction of the bandwidth floor) can be read apart from
+    the knob: acceptance ~0.5 and ~0.8.  One warm-up + two timed generations each, outside the timed region of the headline."""
+    pts = []
+    cur = args.late_damping
+    for d in [float(x) for x in args.operating_points.split(",") if x]:
+        with torch.no_grad():
+            for layer in model.model.layers[E:]:
+                layer.self_attn.o_proj.weight.mul_(d / cur)
+                layer.mlp.down_proj.weight.mul_(d / cur)
+        cur = d
+        strategy.generate_token_ids(model, synthetic.make_prompt(cfg.vocab_size, args.prompt_len, 999), eos, gen)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res, traces = [], []
+        for i in range(2):
+            res.append(strategy.generate_token_ids(model, synthetic.make_prompt(cfg.vocab_size, args.prompt_len, i), eos, gen))
+            traces.append(list(strategy.last_steps))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        toks = sum(len(r.predicted_tokens) for r in res)
+        total_b = 0
+        for steps_i in traces:
+            trace, c, p = [], 0, args.prompt_len
+            for (td, n) in steps_i:
+                trace.append((c, p, td, n))
+                c, p = c + p + n, 1
+            total_b += step_bytes(cfg, E, args.prompt_len, trace)
+        floor_tps = toks / (total_b / (HBM_PEAK_GBS * 1e9))
+        pts.append({"late_damping": d, "acceptance_rate": round(sum(r.acceptance_rate for r in res) / len(res), 4),
+                    "value": round(toks / dt, 2), "unit": "tokens/s", "frac_of_floor": round(toks / dt / floor_tps, 4),
+                    "sample": "2 generations of the headline workload"})
+    with torch.no_grad():                      # back to the headline checkpoint (values are bf16-rescaled, not bit-restored)
+        for layer in model.model.layers[E:]:
+            layer.self_attn.o_proj.weight.mul_(args.late_damping / cur)
+            layer.mlp.down_proj.weight.mul_(args.late_damping / cur)
+    return pts
 
 
 def sampled_leg(args, cfg, model, E, S, eos, greedy_tps):
@@ -331,7 +381,7 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev, backend):
     import torch.distributed as dist
     from layerskip_amd.engine import HipEngine
     from layerskip_amd.pipeline import PipelineSpeculativeDecoder, plan_partition
-    part = plan_partition(cfg.num_hidden_layers, E, world)
+    part = plan_partition(cfg.num_hidden_layers, E, world, balance=args.pp_balance)
     model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=args.late_damping, dtype=torch.bfloat16,
                                   device=dev, gen_device=dev, layer_range=part[rank])
     engine = HipEngine(model, max_ctx=args.prompt_len + args.max_steps + 2 * S + 32, max_prompt=args.prompt_len,
@@ -352,6 +402,10 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev, backend):
     _barrier(world)
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # per-hop latency of the late ranks (host time to enqueue a block's launches, time the host then waited for the message)
+    # next to rank 0's draft / verify round-trip times and the hit rate of its optimistic continuation
+    hop_stats = [None] * world
+    dist.all_gather_object(hop_stats, dec.stats())
     out = None
     if rank == 0:
         tokens = sum(len(r.predicted_tokens) for r in results)
@@ -373,7 +427,13 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev, backend):
             "config": {"workload": f"{args.model} shape, exit_layer={E}, num_speculations={S}, {args.prompt_len}-token prompt, "
                                    f"{args.max_steps} new tokens, batch 1, greedy, random-init weights (late damping {args.late_damping})",
                        "strategy": "self_speculative", "parallelism": f"pp{world}: layer ranges {part}, RCCL point-to-point"},
-            "pipeline": getattr(dec, "stats", lambda: {})(),
+            "pipeline": {**hop_stats[0],
+                         "hops": [{"rank": r, "layers": list(part[r]), "hop_enqueue_ms": st.get("hop_enqueue_ms"), "hop_wait_ms": st.get("hop_wait_ms"),
+                                   "blocks": st.get("hops")} for r, st in enumerate(hop_stats) if r > 0],
+                         "message_bytes_per_hop": (S + 2) * cfg.hidden_size * 2,
+                         "note": "hop_enqueue_ms = host time from posting the receive to forwarding the block (its launches queue behind "
+                                 "the receive); hop_wait_ms = time the host then waited for the header; the device applies the header's "
+                                 "rollback itself (lsk_pipeline_apply), the last rank accepts on the device (lsk_pipeline_tail)"},
             "path_roofline": None if not floor_tps else {
                 "algorithmic_bytes_per_generation": total_b // max(1, len(results)),
                 "floor_tokens_per_s_at_8TBs": round(floor_tps, 1), "frac_of_floor": round(tokens / elapsed / floor_tps, 4),
@@ -452,6 +512,26 @@ def cpu_baseline(args, cfg, model, E, S, strategy, eos):
     pred = []
     for r0 in range(0, len(seq), 16):
         pred += eng.run_head(BUF_BULK, r0, min(16, len(seq) - r0))
+    # logits of the engine vs the oracle's (CPU bf16) on sampled rows of the same teacher-forced sequence
+    rows = sorted(set([0, len(prompt) // 2, len(prompt) - 1] + [len(prompt) - 1 + (len(out) * k) // 8 for k in range(1, 9)]))
+    rows = [r for r in rows if 0 <= r < len(seq)]
+    t0 = time.time()
+    with torch.inference_mode():
+        ref_logits = lo.teacher_forced_logits(om, seq)
+    tf_s = time.time() - t0
+    worst_ulp, max_abs, within, count = 0.0, 0.0, 0, 0
+    for r in rows:
+        buf = torch.empty(1, eng.vocab, dtype=torch.float32, device=eng.device)
+        eng.run_head(BUF_BULK, r, 1, logits=buf, want_tokens=False)
+        mine = buf[0].cpu()
+        ref = ref_logits[r].float()
+        idx = torch.topk(ref, 32).indices
+        err = (mine[idx] - ref[idx]).abs()
+        ulp = torch.pow(2.0, torch.floor(torch.log2(ref[idx].abs().clamp_min(1.0))) - 7)
+        e = err / ulp
+        worst_ulp, max_abs = max(worst_ulp, float(e.max())), max(max_abs, float(err.max()))
+        within += int((e <= 1.0).sum())
+        count += int(idx.numel())
     eng.reset()
     P = len(prompt)
     miss = [i for i in range(len(out)) if pred[P - 1 + i] != out[i]]
@@ -461,9 +541,14 @@ def cpu_baseline(args, cfg, model, E, S, strategy, eos):
                       f"(prompt prefill); weights D2H {copy_s:.1f} s not counted",
             "decode_only_tokens_per_s": None if decode_only is None else round(decode_only, 3),
             "acceptance_rate": round(matches / drafts, 4) if drafts else None,
+            "acceptance_note": f"over {len(out)} new tokens of ONE prompt: not comparable with the headline's acceptance (4 x 512 tokens)",
             "parity_vs_gpu": {"free_running_first_mismatch": first,
                               "oracle_margin_there": None if first is None or first >= len(margins) else round(margins[first], 4),
                               "teacher_forced_argmax_agreement": f"{len(out) - len(miss)}/{len(out)}",
+                              "teacher_forced_logits": {"rows": len(rows), "entries": count, "within_1_bf16_ulp": within,
+                                                        "worst_ulp": round(worst_ulp, 2), "max_abs_err": round(max_abs, 4),
+                                                        "note": f"top-32 logits of {len(rows)} rows of prompt + oracle output, engine vs the oracle's CPU bf16 "
+                                                                f"run ({tf_s:.1f} s); ulp of the reference value, never finer than at |1.0|"},
                               "oracle_margins_at_disagreements": [round(margins[i], 4) for i in miss if i < len(margins)],
                               "note": "random-init weights: their bf16 logits tie at ulp resolution (ulp 0.031 at |logit| 4-8), so this "
                                       "workload cannot show token-exact parity; the token-exact gate is tests/test_gpu_struct_parity.py "

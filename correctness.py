@@ -3,7 +3,9 @@
 outputs must be identical (`--sample False`, README.md:145-156).  Exit code 1 on any mismatch."""
 from __future__ import annotations
 
+import datetime
 import json
+import os
 import sys
 from dataclasses import replace
 
@@ -37,6 +39,9 @@ def main():
             print(f"sample {i}: mismatch at token {first}")
     out = {"errors": errors, "error_pct": errors / max(1, len(prompts)), "num_samples": len(prompts)}
     print(json.dumps(out))
+    os.makedirs(args.output_dir, exist_ok=True)                   # correctness.py:90-99: the result file next to the logs
+    with open(os.path.join(args.output_dir, f"correctness_{datetime.datetime.now().strftime('%Y%m%d_%H%M%S')}.json"), "w") as f:
+        json.dump(out, f)
     sys.exit(1 if errors else 0)
 
 

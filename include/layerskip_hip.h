@@ -115,6 +115,12 @@ int lsk_engine_set_layer(lsk_engine* e, int32_t layer, const void* wqkv, const v
 int lsk_engine_set_globals(lsk_engine* e, const void* embed, const void* final_norm,
                            const void* lm_head, const void* rope_cos, const void* rope_sin,
                            int32_t rope_len);
+/* Sampled 64-bit content checksums of `n` caller tensors of 2-byte elements (device pointers, element counts; up to 4096
+ * evenly strided samples each, first and last element included) -> out_sums (host).  One launch, synchronous.  The host side
+ * compares them with the values taken when it packed the weights: an in-place edit through `.data` (PEFT's LoRA merge) changes
+ * neither a tensor's address nor torch's version counter.  The reference always reads live weights (generator_base.py:109). */
+int lsk_engine_weights_checksum(lsk_engine* e, const void* const* tensors, const int64_t* n_elems, int32_t n,
+                                uint64_t* out_sums, void* stream);
 /* Logical page -> physical page of the KV pool (host array, copied).  Default: identity. */
 int lsk_engine_set_block_table(lsk_engine* e, const int32_t* table, int32_t n_pages, void* stream);
 
@@ -177,6 +183,20 @@ int lsk_ar_generate(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int3
  * what rank 0 does optimistically while a verify block is in flight.  Nothing is waited for. */
 int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows,
                     int32_t pos_off0, int32_t exit_layer, int32_t head_last, void* stream);
+/* The verify block travels rank to rank as ONE message: buffer 2 (LSK_MAX_ROWS + 1 rows), row 0 = a header of int32 words
+ * {magic, go, prompt_len, rows, verified context length, draft ids[16]}, rows 1.. = the hidden rows.  No rank reads the header on
+ * the host before it has enqueued the step:
+ *   lsk_pipeline_pack  (rank 0)     step rows [src_row, src_row + m) -> message rows [1, 1 + m), header from the arguments and the
+ *                                   device-resident draft tokens; go = 0: header only (the final verified length);
+ *   lsk_pipeline_apply (ranks > 0)  the header's rollback (crop_past_key_values, SSG:219-221) applied on the DEVICE; kv_bound = the
+ *                                   host's upper bound of the context (bounds checks, attention pages);
+ *   lsk_pipeline_tail  (last rank)  final norm + lm_head + argmax over message rows [1, 1 + m), then the wavefront-ballot acceptance
+ *                                   (SSG:186-190) against the header's drafts: result_dev (DEVICE int32[64]) = {num_matches,
+ *                                   num_drafts, next_token, kv_len, emitted[17], ...}; the first 24 words are what rank 0 needs. */
+int lsk_engine_set_eos(lsk_engine* e, const int32_t* eos_token_ids, int32_t n_eos, void* stream);
+int lsk_pipeline_pack(lsk_engine* e, int32_t go, int32_t prompt_len, int32_t src_row, int32_t m, int32_t kv, void* stream);
+int lsk_pipeline_apply(lsk_engine* e, int32_t kv_bound, void* stream);
+int lsk_pipeline_tail(lsk_engine* e, int32_t m, void* result_dev, void* stream);
 /* tokens of step rows [row0, row0 + n) (row 0 = the input token, row j = draft j): HOST int32[n]; synchronises */
 int lsk_get_row_tokens(lsk_engine* e, int32_t row0, int32_t n, int32_t* out, void* stream);
 /* move step rows (hidden rows + tokens) [src, src+n) down to [dst, dst+n), dst < src */
@@ -187,7 +207,7 @@ int lsk_rows_offset(lsk_engine* e, int32_t buffer, int32_t row_base, size_t* out
 /* ---- building blocks (slow path with logits processors / sampling, and kernel parity tests) -- */
 
 /* h[buffer][row_base + i] = embed_tokens(ids[i])  (llama_model_utils.py:182,242,310).
- * buffer: 0 = the 16-row step buffer, 1 = the bulk (prompt) buffer. */
+ * buffer: 0 = the 16-row step buffer, 1 = the bulk (prompt) buffer, 2 = the layer pipeline's message buffer (row 0 = header). */
 int lsk_embed_rows(lsk_engine* e, const int32_t* ids, int32_t n, int32_t buffer, int32_t row_base,
                    void* stream);
 /* Run decoder layers [layer_begin, layer_end) in place over rows [row_base, row_base+m) of

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "lsk_engine_destroy": (c_int32, [c_void_p]),
     "lsk_engine_set_layer": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsk_engine_set_globals": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
+    "lsk_engine_weights_checksum": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(ctypes.c_int64), c_int32, POINTER(c_uint64), c_void_p]),
     "lsk_engine_set_block_table": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_void_p]),
     "lsk_engine_reset": (c_int32, [c_void_p, c_void_p]),
     "lsk_engine_set_kv_len": (c_int32, [c_void_p, c_int32, c_void_p]),
@@ -69,6 +70,10 @@ PROTOTYPES = {
     "lsk_ar_generate": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, POINTER(c_int32), c_int32, c_int32,
                                   POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "lsk_draft_block": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_engine_set_eos": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_void_p]),
+    "lsk_pipeline_pack": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "lsk_pipeline_apply": (c_int32, [c_void_p, c_int32, c_void_p]),
+    "lsk_pipeline_tail": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),
     "lsk_get_row_tokens": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32), c_void_p]),
     "lsk_shift_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "lsk_rows_offset": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_size_t)]),

@@ -12,9 +12,9 @@
 #define LSK_RES_DRAFT 21
 #define LSK_RES_VERIFIED 37
 #define LSK_RES_INTS 54
-__global__ void lsk_accept_kernel(int* __restrict__ draft, const int* __restrict__ verified, int num_drafts,
-                                  const int* __restrict__ eos, int n_eos, int prompt_len, StepState* st,
-                                  int* __restrict__ result) {
+__device__ __forceinline__ void lsk_accept_body(const int* __restrict__ draft, int* __restrict__ next_input, const int* __restrict__ verified,
+                                                int num_drafts, const int* __restrict__ eos, int n_eos, int prompt_len, StepState* st,
+                                                int* __restrict__ result) {
     const int lane = threadIdx.x;
     int d = -1, v = -2;
     bool is_eos = false;
@@ -40,9 +40,67 @@ __global__ void lsk_accept_kernel(int* __restrict__ draft, const int* __restrict
             kv = st->kv_len + prompt_len + n;
             st->kv_len = kv;
             st->next_token = next;
-            draft[-1] = next;          // row_tokens[0]: input token of the next step
+            if (next_input != nullptr) *next_input = next;      // row_tokens[0]: input token of the next step
         }
         result[3] = kv;
         result[LSK_RES_EMIT + n] = next;
     }
+}
+
+__global__ void lsk_accept_kernel(int* __restrict__ draft, const int* __restrict__ verified, int num_drafts,
+                                  const int* __restrict__ eos, int n_eos, int prompt_len, StepState* st,
+                                  int* __restrict__ result) {
+    lsk_accept_body(draft, st != nullptr ? draft - 1 : nullptr, verified, num_drafts, eos, n_eos, prompt_len, st, result);
+}
+
+// ---- layer pipeline: the header that travels in front of a verify block, rank to rank --------------------
+// int32 words of message row 0.  Everything a late rank needs of a step is IN the message, on the device: no rank reads
+// it on the host before it has enqueued the step's launches.
+#define LSK_HDR_MAGIC 0
+#define LSK_HDR_GO 1          // 0: the generation is over (the message only carries the final verified length)
+#define LSK_HDR_P 2           // new tokens in front of the block: the prompt length on the first step, 1 afterwards
+#define LSK_HDR_ROWS 3        // valid rows of the block (num_drafts + 1)
+#define LSK_HDR_KV 4          // verified context length BEFORE this step: the previous step's rollback (crop_past_key_values)
+#define LSK_HDR_DRAFTS 5      // [16] the draft token ids (the last rank's acceptance kernel compares them with its argmaxes)
+#define LSK_HDR_WORDS 24
+#define LSK_HDR_MAGIC_VALUE 0x4c534b31
+
+// rank 0: step rows [src_row, src_row + m) of the step buffer -> message rows [1, 1 + m); header from the arguments and the
+// device-resident draft tokens (row_tokens[src_row + 1 ...])
+__global__ void lsk_pipeline_pack_kernel(const elem_t* __restrict__ hrow, const int* __restrict__ row_tokens, int src_row, int m, int hidden,
+                                         int go, int prompt_len, int kv, elem_t* __restrict__ msg) {
+    if (blockIdx.x == 0) {
+        int* hdr = (int*)msg;
+        if (threadIdx.x < LSK_HDR_WORDS) {
+            const int t = threadIdx.x;
+            int v = 0;
+            if (t == LSK_HDR_MAGIC) v = LSK_HDR_MAGIC_VALUE;
+            else if (t == LSK_HDR_GO) v = go;
+            else if (t == LSK_HDR_P) v = prompt_len;
+            else if (t == LSK_HDR_ROWS) v = m;
+            else if (t == LSK_HDR_KV) v = kv;
+            else if (t >= LSK_HDR_DRAFTS && t < LSK_HDR_DRAFTS + m - 1) v = row_tokens[src_row + 1 + (t - LSK_HDR_DRAFTS)];
+            hdr[t] = v;
+        }
+        return;
+    }
+    const int r = blockIdx.x - 1;
+    const elem8* src = (const elem8*)(hrow + (size_t)(src_row + r) * hidden);
+    elem8* dst = (elem8*)(msg + (size_t)(1 + r) * hidden);
+    for (int i = threadIdx.x; i < hidden / 8; i += blockDim.x) dst[i] = src[i];
+}
+
+// a late rank: the rollback the header carries, applied on the device (the host only keeps an upper bound)
+__global__ void lsk_pipeline_apply_kernel(const elem_t* __restrict__ msg, StepState* st) {
+    const int* hdr = (const int*)msg;
+    if (hdr[LSK_HDR_MAGIC] != LSK_HDR_MAGIC_VALUE) return;     // not a header: the host raises when it reads the words
+    st->kv_len = hdr[LSK_HDR_KV];
+}
+
+// the last rank: acceptance straight from the header's drafts and its own argmaxes; the <= 96-byte result goes back to rank 0
+__global__ void lsk_pipeline_accept_kernel(const elem_t* __restrict__ msg, const int* __restrict__ verified, const int* __restrict__ eos, int n_eos,
+                                           StepState* st, int* __restrict__ result) {
+    const int* hdr = (const int*)msg;
+    const int rows = min(max(hdr[LSK_HDR_ROWS], 1), LSK_ROWS);
+    lsk_accept_body(hdr + LSK_HDR_DRAFTS, nullptr, verified, rows - 1, eos, n_eos, hdr[LSK_HDR_P], st, result);
 }

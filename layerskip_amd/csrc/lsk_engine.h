@@ -30,6 +30,7 @@ struct lsk_engine {
     float* part_val = nullptr;    // [max_parts][16]
     int* part_idx = nullptr;
     elem_t* hrow = nullptr;       // [16][H]
+    elem_t* hmsg = nullptr;       // [1 + 16][H] layer-pipeline message: row 0 = header (int32 words), rows 1.. = the verify block
     elem_t* hbulk = nullptr;      // [max_prompt][H]
     elem_t* qbuf = nullptr;       // [16][n_heads*hd]
     elem_t* attn = nullptr;       // [16][n_heads*hd]
@@ -47,6 +48,8 @@ struct lsk_engine {
     int kv_len_host = 0;          // mirror of state->kv_len
     int next_token_host = -1;     // mirror of row_tokens[0] after a step (-1: unknown)
     int* host_result = nullptr;   // pinned [2][64]: result blocks of the (up to two) steps in flight
+    unsigned long long* host_sums = nullptr;   // pinned, device-visible: [cap] tensor addresses | [cap] element counts | [cap] checksums
+    int host_sums_cap = 0;
     hipEvent_t step_done[2] = {nullptr, nullptr};
     int eos_host[LSK_MAX_EOS]; int n_eos_host = -1;
     int target_wgs = 256;
@@ -59,7 +62,7 @@ struct lsk_engine {
     bool graph_steps = false;
     int graph_pages = 0;          // > 0 while a step is captured / replayed: every attention launch covers this many pages
     hipStream_t own_stream = nullptr;   // capture needs a non-default stream; torch's current stream is usually the null stream
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipEvent_t fork_ev = nullptr;
     struct StepGraph { int S, E, n_eos, slot, pages; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
     // host-side cost of the fused generate calls: time this thread spent enqueueing steps vs the wall time of the call
@@ -73,6 +76,9 @@ struct lsk_engine {
 enum { LSK_PROF_QKV = 0, LSK_PROF_ATTN = 1, LSK_PROF_OPROJ = 2, LSK_PROF_GATEUP = 3, LSK_PROF_DOWN = 4, LSK_PROF_HEAD = 5, LSK_PROF_CLASSES = 6 };
 
 int lsk_check_cfg(const lsk_config* c);
+// rows of a hidden-state buffer (0 = step rows, 1 = bulk / prompt rows, 2 = pipeline message rows) and their capacity
+elem_t* lsk_buf_rows(lsk_engine* e, int buffer, int row_base);
+int lsk_buf_capacity(lsk_engine* e, int buffer);
 int lsk_ready(lsk_engine* e);
 int lsk_layers_bound(lsk_engine* e, int lb, int le);
 int lsk_set_kv_len_dev(lsk_engine* e, int kv_len, bool add, hipStream_t st);

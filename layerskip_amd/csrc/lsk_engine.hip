@@ -35,7 +35,7 @@ __global__ void lsk_set_state_kernel(StepState* st, int kv_len, int add) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-    size_t state, zero, block_table, row_tokens, verified, eos, result, bulk_ids, part_val, part_idx, hrow, hbulk, qbuf,
+    size_t state, zero, block_table, row_tokens, verified, eos, result, bulk_ids, part_val, part_idx, hrow, hmsg, hbulk, qbuf,
         attn, act, attn_part, attn_cnt, xn_bulk, q_bulk, attn_bulk, act_bulk, total;
     int max_parts, n_pages;
 };
@@ -71,6 +71,7 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.part_val = take(sizeof(float) * 16 * (size_t)L.max_parts);
     L.part_idx = take(sizeof(int) * 16 * (size_t)L.max_parts);
     L.hrow = take(2 * (size_t)LSK_MAX_ROWS * c->hidden);
+    L.hmsg = take(2 * (size_t)(LSK_MAX_ROWS + 1) * c->hidden);
     L.hbulk = take(2 * (size_t)(c->max_prompt + 16) * c->hidden);
     L.qbuf = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
     L.attn = take(2 * (size_t)LSK_MAX_ROWS * c->n_heads * c->head_dim);
@@ -151,6 +152,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->part_val = (float*)(e->ws + L.part_val);
     e->part_idx = (int*)(e->ws + L.part_idx);
     e->hrow = (elem_t*)(e->ws + L.hrow);
+    e->hmsg = (elem_t*)(e->ws + L.hmsg);
     e->hbulk = (elem_t*)(e->ws + L.hbulk);
     e->qbuf = (elem_t*)(e->ws + L.qbuf);
     e->attn = (elem_t*)(e->ws + L.attn);
@@ -186,10 +188,10 @@ extern "C" int lsk_engine_destroy(lsk_engine* e) {
     if (!e) return 0;
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->host_result) (void)hipHostFree(e->host_result);
+    if (e->host_sums) (void)hipHostFree(e->host_sums);
     for (int i = 0; i < 2; ++i) if (e->step_done[i]) (void)hipEventDestroy(e->step_done[i]);
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
-    if (e->join_ev) (void)hipEventDestroy(e->join_ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return 0;
@@ -211,6 +213,57 @@ extern "C" int lsk_engine_set_globals(lsk_engine* e, const void* embed, const vo
     if (rope_len < e->cfg.max_ctx) return lsk_fail("rope table (%d) shorter than max_ctx (%d)", rope_len, e->cfg.max_ctx);
     e->embed = (const elem_t*)embed; e->final_norm = (const elem_t*)final_norm; e->lm_head = (const elem_t*)lm_head;
     e->rope_cos = (const elem_t*)rope_cos; e->rope_sin = (const elem_t*)rope_sin; e->rope_len = rope_len;
+    return 0;
+}
+
+// One workgroup per tensor: a 64-bit checksum over up to 4096 evenly strided 2-byte elements (first and last included).
+// The sum is of (value + 1) * odd(index) terms modulo 2^64: order-independent, so the reduction order is free.
+#define LSK_SUM_SAMPLES 4096
+__global__ void lsk_checksum_kernel(const unsigned long long* __restrict__ ptrs, const unsigned long long* __restrict__ numels,
+                                    unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long part[4];
+    const unsigned short* t = (const unsigned short*)ptrs[blockIdx.x];
+    const unsigned long long n = numels[blockIdx.x];
+    const unsigned long long ns = n < LSK_SUM_SAMPLES ? n : LSK_SUM_SAMPLES;
+    unsigned long long acc = 0;
+    for (unsigned long long k = threadIdx.x; k < ns; k += blockDim.x) {
+        const unsigned long long idx = ns > 1 ? (k * (n - 1)) / (ns - 1) : 0;
+        acc += ((unsigned long long)t[idx] + 1ull) * ((2ull * k + 1ull) * 0x9E3779B97F4A7C15ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3] + n;
+}
+
+// Sampled content checksums of caller tensors (2-byte elements), for the host's "did the weights change under the packed
+// copies" check: an in-place edit through `.data` (a LoRA merge) moves neither the address nor torch's version counter.
+extern "C" int lsk_engine_weights_checksum(lsk_engine* e, const void* const* tensors, const int64_t* n_elems, int32_t n,
+                                           uint64_t* out_sums, void* stream) {
+    if (!e || !tensors || !n_elems || !out_sums || n < 1) return lsk_fail("lsk_engine_weights_checksum: bad arguments");
+    if (n > e->host_sums_cap) {
+        if (e->host_sums) (void)hipHostFree(e->host_sums);
+        e->host_sums = nullptr; e->host_sums_cap = 0;
+        HIP_OK(hipHostMalloc((void**)&e->host_sums, sizeof(unsigned long long) * 3 * (size_t)n, hipHostMallocDefault));
+        e->host_sums_cap = n;
+    }
+    unsigned long long* ptrs = e->host_sums;
+    unsigned long long* cnts = ptrs + e->host_sums_cap;
+    unsigned long long* sums = cnts + e->host_sums_cap;
+    for (int i = 0; i < n; ++i) {
+        if (!tensors[i] || n_elems[i] < 1) return lsk_fail("lsk_engine_weights_checksum: tensor %d is empty", i);
+        ptrs[i] = (unsigned long long)(uintptr_t)tensors[i];
+        cnts[i] = (unsigned long long)n_elems[i];
+        sums[i] = 0;
+    }
+    unsigned long long* dptr = nullptr;
+    HIP_OK(hipHostGetDevicePointer((void**)&dptr, ptrs, 0));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lsk_checksum_kernel, dim3(n), dim3(256), 0, st, dptr, dptr + e->host_sums_cap, dptr + 2 * (size_t)e->host_sums_cap);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) out_sums[i] = sums[i];
     return 0;
 }
 
@@ -278,14 +331,19 @@ static int profile_pair(lsk_engine* e, int cat, int m, double bytes, hipEvent_t*
     return 0;
 }
 
-static elem_t* buf_rows(lsk_engine* e, int buffer, int row_base) {
-    return (buffer == 0 ? e->hrow : e->hbulk) + (size_t)row_base * e->cfg.hidden;
+elem_t* lsk_buf_rows(lsk_engine* e, int buffer, int row_base) {
+    elem_t* base = buffer == 0 ? e->hrow : (buffer == 1 ? e->hbulk : e->hmsg);
+    return base + (size_t)row_base * e->cfg.hidden;
+}
+
+int lsk_buf_capacity(lsk_engine* e, int buffer) {
+    return buffer == 0 ? LSK_MAX_ROWS : (buffer == 1 ? e->cfg.max_prompt + 16 : LSK_MAX_ROWS + 1);
 }
 
 static int check_rows(lsk_engine* e, int buffer, int row_base, int m) {
-    if (buffer != 0 && buffer != 1) return lsk_fail("bad buffer %d", buffer);
+    if (buffer < 0 || buffer > 2) return lsk_fail("bad buffer %d", buffer);
     if (m < 1 || m > LSK_MAX_ROWS) return lsk_fail("row count %d out of range 1..%d", m, LSK_MAX_ROWS);
-    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
+    const int cap = lsk_buf_capacity(e, buffer);
     if (row_base < 0 || row_base + m > cap) return lsk_fail("rows [%d,%d) exceed buffer %d capacity %d", row_base, row_base + m, buffer, cap);
     return 0;
 }
@@ -536,9 +594,8 @@ int lsk_check_ids(lsk_engine* e, const int32_t* ids, int n) {
 // (point-to-point send / recv straight from / into the engine's buffers).
 extern "C" int lsk_rows_offset(lsk_engine* e, int32_t buffer, int32_t row_base, size_t* out_offset) {
     if (!e || !out_offset) return lsk_fail("lsk_rows_offset: null pointer");
-    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
-    if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base >= cap) return lsk_fail("lsk_rows_offset: rows out of range");
-    *out_offset = (size_t)((unsigned char*)buf_rows(e, buffer, row_base) - e->ws);
+    if (buffer < 0 || buffer > 2 || row_base < 0 || row_base >= lsk_buf_capacity(e, buffer)) return lsk_fail("lsk_rows_offset: rows out of range");
+    *out_offset = (size_t)((unsigned char*)lsk_buf_rows(e, buffer, row_base) - e->ws);
     return 0;
 }
 
@@ -546,13 +603,12 @@ extern "C" int lsk_rows_offset(lsk_engine* e, int32_t buffer, int32_t row_base, 
 extern "C" int lsk_embed_rows(lsk_engine* e, const int32_t* ids, int32_t n, int32_t buffer, int32_t row_base, void* stream) {
     LSK_TRY(lsk_ready(e));
     if (!ids || n < 1) return lsk_fail("lsk_embed_rows: bad arguments");
-    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
-    if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base + n > cap) return lsk_fail("lsk_embed_rows: rows out of range");
+    if (buffer < 0 || buffer > 2 || row_base < 0 || row_base + n > lsk_buf_capacity(e, buffer)) return lsk_fail("lsk_embed_rows: rows out of range");
     if (n > e->cfg.max_prompt + 16) return lsk_fail("lsk_embed_rows: too many ids");
     LSK_TRY(lsk_check_ids(e, ids, n));
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(hipMemcpyAsync(e->bulk_ids, ids, sizeof(int) * n, hipMemcpyHostToDevice, st));
-    return lsk_embed_rows_dev(e, e->bulk_ids, n, buf_rows(e, buffer, row_base), st);
+    return lsk_embed_rows_dev(e, e->bulk_ids, n, lsk_buf_rows(e, buffer, row_base), st);
 }
 
 extern "C" int lsk_run_layers(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, int32_t pos_offset, int32_t layer_begin,
@@ -562,7 +618,7 @@ extern "C" int lsk_run_layers(lsk_engine* e, int32_t buffer, int32_t row_base, i
     if (layer_begin < 0 || layer_end > e->cfg.num_layers || layer_begin > layer_end) return lsk_fail("bad layer range [%d,%d)", layer_begin, layer_end);
     if (pos_offset < 0 || e->kv_len_host + pos_offset + m > e->cfg.max_ctx) return lsk_fail("positions exceed max_ctx");
     LSK_TRY(lsk_layers_bound(e, layer_begin, layer_end));
-    return lsk_run_layers_dev(e, buf_rows(e, buffer, row_base), m, &e->state->kv_len, pos_offset, layer_begin, layer_end, (hipStream_t)stream);
+    return lsk_run_layers_dev(e, lsk_buf_rows(e, buffer, row_base), m, &e->state->kv_len, pos_offset, layer_begin, layer_end, (hipStream_t)stream);
 }
 
 extern "C" int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_end, void* stream) {
@@ -592,7 +648,7 @@ extern "C" int lsk_run_head(lsk_engine* e, int32_t buffer, int32_t row_base, int
     LSK_TRY(check_rows(e, buffer, row_base, m));
     if (logits_out && ld_logits < e->cfg.vocab) return lsk_fail("ld_logits %d < vocab %d", ld_logits, e->cfg.vocab);
     hipStream_t st = (hipStream_t)stream;
-    LSK_TRY(lsk_run_head_dev(e, buf_rows(e, buffer, row_base), m, (float*)logits_out, ld_logits, e->verified, st));
+    LSK_TRY(lsk_run_head_dev(e, lsk_buf_rows(e, buffer, row_base), m, (float*)logits_out, ld_logits, e->verified, st));
     if (tokens_out) {
         HIP_OK(hipMemcpyAsync(tokens_out, e->verified, sizeof(int) * m, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -602,17 +658,15 @@ extern "C" int lsk_run_head(lsk_engine* e, int32_t buffer, int32_t row_base, int
 
 extern "C" int lsk_read_rows(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, void* dst, void* stream) {
     if (!e || !dst || m < 1) return lsk_fail("lsk_read_rows: bad arguments");
-    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
-    if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base + m > cap) return lsk_fail("lsk_read_rows: rows out of range");
-    HIP_OK(hipMemcpyAsync(dst, buf_rows(e, buffer, row_base), (size_t)m * e->cfg.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (buffer < 0 || buffer > 2 || row_base < 0 || row_base + m > lsk_buf_capacity(e, buffer)) return lsk_fail("lsk_read_rows: rows out of range");
+    HIP_OK(hipMemcpyAsync(dst, lsk_buf_rows(e, buffer, row_base), (size_t)m * e->cfg.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 
 extern "C" int lsk_write_rows(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, const void* src, void* stream) {
     if (!e || !src || m < 1) return lsk_fail("lsk_write_rows: bad arguments");
-    const int cap = buffer == 0 ? LSK_MAX_ROWS : e->cfg.max_prompt + 16;
-    if ((buffer != 0 && buffer != 1) || row_base < 0 || row_base + m > cap) return lsk_fail("lsk_write_rows: rows out of range");
-    HIP_OK(hipMemcpyAsync(buf_rows(e, buffer, row_base), src, (size_t)m * e->cfg.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (buffer < 0 || buffer > 2 || row_base < 0 || row_base + m > lsk_buf_capacity(e, buffer)) return lsk_fail("lsk_write_rows: rows out of range");
+    HIP_OK(hipMemcpyAsync(lsk_buf_rows(e, buffer, row_base), src, (size_t)m * e->cfg.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 

@@ -128,8 +128,9 @@ static int enqueue_step_graph(lsk_engine* e, int S, int E, int n_eos, int slot, 
         if (g.S == S && g.E == E && g.n_eos == n_eos && g.slot == slot && g.pages == pages) { exec = g.exec; break; }
     if (exec == nullptr) {
         hipGraph_t graph = nullptr;
-        e->graph_pages = pages;
-        HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const hipError_t berr = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (berr != hipSuccess) return lsk_fail("hipStreamBeginCapture failed: %s", hipGetErrorString(berr));
+        e->graph_pages = pages;            // every exit below clears it again
         const int rc = enqueue_step_body(e, 1, S, E, n_eos, slot, st, nullptr);
         const hipError_t err = hipStreamEndCapture(st, &graph);
         e->graph_pages = 0;
@@ -210,7 +211,6 @@ static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t 
         if (!e->own_stream) {
             HIP_OK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
             HIP_OK(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
-            HIP_OK(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
         }
         HIP_OK(hipEventRecord(e->fork_ev, caller));
         HIP_OK(hipStreamWaitEvent(e->own_stream, e->fork_ev, 0));
@@ -289,9 +289,11 @@ static int spec_generate_impl(lsk_engine* e, const int32_t* prompt_ids, int32_t 
         pend_P = 1;
         slot = next_slot;
     }
-    HIP_OK(hipStreamSynchronize(st));
-    // leave the engine consistent with the device: the verified length (a drained redundant step may have moved it)
+    // leave the engine consistent with the device: the verified length (a drained redundant step may have moved it).  Enqueued
+    // BEFORE the final wait, on the stream the generation ran on (the engine's own one under LSK_OPT_GRAPH_STEPS): when the call
+    // returns nothing of it is in flight any more, whichever stream the caller uses next.
     LSK_TRY(lsk_set_kv_len_dev(e, kv_true, false, st));
+    HIP_OK(hipStreamSynchronize(st));
     e->next_token_host = -1;
 #undef LSK_TIMED_ENQUEUE
     e->host_enqueue_s += enq_s;
@@ -433,6 +435,42 @@ extern "C" int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t 
         LSK_TRY(lsk_run_layers_dev(e, xr, 1, kvp, pos_off0 + j, 0, E, st));
         if (j + 1 < n_rows || head_last) LSK_TRY(lsk_run_head_dev(e, xr, 1, nullptr, 0, e->row_tokens + row0 + j + 1, st, xr + c.hidden));
     }
+    return 0;
+}
+
+// ---- layer-range pipeline: the verify block as ONE message per hop, its header applied on the device ----------------------
+extern "C" int lsk_engine_set_eos(lsk_engine* e, const int32_t* eos_token_ids, int32_t n_eos, void* stream) {
+    if (!e || n_eos < 0 || n_eos > LSK_MAX_EOS || (n_eos > 0 && !eos_token_ids)) return lsk_fail("lsk_engine_set_eos: bad eos list");
+    return upload_step_inputs(e, nullptr, 0, eos_token_ids, n_eos, (hipStream_t)stream);
+}
+
+extern "C" int lsk_pipeline_pack(lsk_engine* e, int32_t go, int32_t prompt_len, int32_t src_row, int32_t m, int32_t kv, void* stream) {
+    LSK_TRY(lsk_ready(e));
+    if (m < 1 || src_row < 0 || src_row + m > LSK_MAX_ROWS) return lsk_fail("lsk_pipeline_pack: rows [%d,%d) exceed the step buffer", src_row, src_row + m);
+    if (prompt_len < 0 || kv < 0 || kv > e->cfg.max_ctx) return lsk_fail("lsk_pipeline_pack: bad header values");
+    hipLaunchKernelGGL(lsk_pipeline_pack_kernel, dim3(1 + (go ? m : 0)), dim3(256), 0, (hipStream_t)stream, e->hrow, e->row_tokens, src_row, m,
+                       e->cfg.hidden, go ? 1 : 0, prompt_len, kv, e->hmsg);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lsk_pipeline_apply(lsk_engine* e, int32_t kv_bound, void* stream) {
+    if (!e || kv_bound < 0 || kv_bound > e->cfg.max_ctx) return lsk_fail("lsk_pipeline_apply: context bound %d out of range", kv_bound);
+    hipLaunchKernelGGL(lsk_pipeline_apply_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->hmsg, e->state);
+    HIP_OK(hipGetLastError());
+    e->kv_len_host = kv_bound;        // an UPPER bound is all the host side needs (bounds checks, attention pages to launch)
+    e->next_token_host = -1;
+    return 0;
+}
+
+extern "C" int lsk_pipeline_tail(lsk_engine* e, int32_t m, void* result_dev, void* stream) {
+    LSK_TRY(lsk_ready(e));
+    if (m < 1 || m > LSK_MAX_ROWS || !result_dev) return lsk_fail("lsk_pipeline_tail: bad arguments");
+    if (e->n_eos_host < 0) return lsk_fail("lsk_pipeline_tail: eos list not set (lsk_engine_set_eos)");
+    hipStream_t st = (hipStream_t)stream;
+    LSK_TRY(lsk_run_head_dev(e, e->hmsg + e->cfg.hidden, m, nullptr, 0, e->verified, st));
+    hipLaunchKernelGGL(lsk_pipeline_accept_kernel, dim3(1), dim3(64), 0, st, e->hmsg, e->verified, e->eos, e->n_eos_host, e->state, (int*)result_dev);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 

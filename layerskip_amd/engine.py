@@ -22,6 +22,7 @@ from ._lib import LskConfig, LskStepResult
 
 BUF_STEP = 0   # 16-row step buffer (draft rows / verify block)
 BUF_BULK = 1   # prompt rows (prefill), doubles as the exit_query_cache of the first step
+BUF_MSG = 2    # the layer pipeline's message: row 0 = header words, rows 1.. = the verify block (lsk_pipeline_*)
 
 
 @dataclass
@@ -120,22 +121,35 @@ class HipEngine:
         return self._model_ref()
 
     # ------------------------------------------------------------------ weights
-    def _weights_fingerprint(self, m):
-        """(storage address, in-place version) of every tensor the engine copied or borrowed.  load_state_dict(), an
-        in-place edit or a LoRA merge bumps the version; assigning a new Parameter changes the address."""
-        if self.release_weights:
-            return None                      # the originals were dropped: the model object only serves this engine
-        fp = []
+    def _weight_tensors(self, m):
+        out = []
         for idx, layer in enumerate(m.model.layers):
             if not (self.layer_range[0] <= idx < self.layer_range[1]):
                 continue
             a, mlp = layer.self_attn, layer.mlp
-            for t in (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight,
-                      mlp.down_proj.weight, layer.input_layernorm.weight, layer.post_attention_layernorm.weight):
-                fp.append((t.data_ptr(), t._version))
-        for t in (m.lm_head.weight, m.model.embed_tokens.weight, m.model.norm.weight):
-            fp.append((t.data_ptr(), t._version))
-        return tuple(fp)
+            out += [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight,
+                    mlp.down_proj.weight, layer.input_layernorm.weight, layer.post_attention_layernorm.weight]
+        out += [m.lm_head.weight, m.model.embed_tokens.weight, m.model.norm.weight]
+        return out
+
+    def _weights_fingerprint(self, m):
+        """What the engine copied or borrowed, in two parts: (storage address, in-place version) of every tensor --
+        load_state_dict(), an in-place op on the Parameter or assigning a new Parameter shows there -- and a sampled CONTENT
+        checksum per tensor (lsk_engine_weights_checksum: up to 4096 evenly strided elements each, one launch), because an
+        edit through `.data` (`p.data += delta`: PEFT's default LoRA merge) moves neither the address nor the version.  An edit
+        confined to elements the sample misses is not detected: call refresh_weights() after such surgery."""
+        if self.release_weights:
+            return None                      # the originals were dropped: the model object only serves this engine
+        tensors = self._weight_tensors(m)
+        meta = tuple((t.data_ptr(), t._version) for t in tensors)
+        if not self._handle or any(t.device != self.device or t.element_size() != 2 or not t.is_contiguous() for t in tensors):
+            return (meta, None)
+        n = len(tensors)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        cnts = (ctypes.c_int64 * n)(*[t.numel() for t in tensors])
+        sums = (ctypes.c_uint64 * n)()
+        self._ck(self.lib.lsk_engine_weights_checksum(self._handle, ptrs, cnts, n, sums, self._stream))
+        return (meta, tuple(sums))
 
     def weights_changed(self, model=None) -> bool:
         model = model if model is not None else self.model
@@ -423,6 +437,32 @@ class HipEngine:
         self._ck(self.lib.lsk_draft_block(self._handle, ids, n, int(row0), int(n_rows), int(pos_off0), int(exit_layer),
                                        1 if head_last else 0, self._stream))
 
+    def set_eos(self, eos_token_ids: Sequence[int]) -> None:
+        """The eos list of the acceptance kernel (pipeline ranks: lsk_engine_set_eos)."""
+        eos, arr = self._eos_array(eos_token_ids)
+        self._ck(self.lib.lsk_engine_set_eos(self._handle, arr, len(eos), self._stream))
+
+    def pipeline_pack(self, go: int, prompt_len: int, src_row: int, m: int, kv: int) -> None:
+        """Rank 0: step rows [src_row, src_row + m) + header -> the message buffer (lsk_pipeline_pack), asynchronous."""
+        self._ck(self.lib.lsk_pipeline_pack(self._handle, int(go), int(prompt_len), int(src_row), int(m), int(kv), self._stream))
+
+    def pipeline_apply(self, kv_bound: int) -> None:
+        """Ranks > 0: the received header's rollback applied on the device; the host keeps `kv_bound` (lsk_pipeline_apply)."""
+        self._ck(self.lib.lsk_pipeline_apply(self._handle, int(min(kv_bound, self.max_ctx)), self._stream))
+
+    def pipeline_tail(self, m: int) -> torch.Tensor:
+        """Last rank: head + argmax + acceptance kernel over message rows [1, 1 + m) -> device int32[64] result block."""
+        res = self._buffers.get("pp_result")
+        if res is None:
+            res = torch.zeros(64, dtype=torch.int32, device=self.device)
+            self._buffers["pp_result"] = res
+        self._ck(self.lib.lsk_pipeline_tail(self._handle, int(m), res.data_ptr(), self._stream))
+        return res
+
+    def header(self) -> List[int]:
+        """The int32 words of the message header (synchronises: a device -> host read)."""
+        return [int(v) for v in self.rows_view(BUF_MSG, 0, 1).view(torch.int32)[0, :24].tolist()]
+
     def row_tokens(self, row0: int, n: int) -> List[int]:
         out = (ctypes.c_int32 * n)()
         self._ck(self.lib.lsk_get_row_tokens(self._handle, int(row0), int(n), out, self._stream))
@@ -539,8 +579,8 @@ def get_engine(model, check_weights: bool = True, **kwargs) -> HipEngine:
 
     The engine streams PACKED COPIES of the projections, so it must notice when the model's weights change under it
     (load_state_dict, an in-place edit, a LoRA merge on the same object -- the reference always reads live weights):
-    with ``check_weights`` the (address, version) fingerprint taken at pack time is compared and the weights are
-    re-packed on a mismatch.  Keyword arguments that differ from the cached engine's are applied where that is possible
+    with ``check_weights`` the fingerprint taken at pack time -- (address, version) per tensor plus a sampled content
+    checksum, which is what catches edits through ``.data`` -- is compared and the weights are re-packed on a mismatch.  Keyword arguments that differ from the cached engine's are applied where that is possible
     (capacity grows, target_wgs is an option) and reported otherwise."""
     global _ENGINES
     if _ENGINES is None:

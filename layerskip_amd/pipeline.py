@@ -7,16 +7,20 @@ This module is the MI355X-native form of that partition (SURVEY.md section 8e, B
 
 * rank 0 owns the embedding, decoder layers `[0, b0)` with `b0 >= exit_layer`, and a copy of the final
   norm + lm_head: the whole draft loop (`forward_early` x S, LMU:213-276) is rank-local and DEVICE-RESIDENT --
-  one asynchronous `lsk_draft_block` call, each argmax embedded into the next row on the device, one host read of the
-  S draft ids at the end (the reference: one sync and one upload per draft token, SSG:141,145);
+  one asynchronous `lsk_draft_block` call, each argmax embedded into the next row on the device;
 * the remaining layers are split in contiguous ranges over ranks 1..N-1; the verify block
-  (`exit_query_cache || last draft` = T_d+1 hidden rows, LMU:364-383) is streamed rank to rank with
-  point-to-point `send/recv` straight from / into the engines' row buffers (RCCL over one xGMI link per hop:
-  (T_d+1) x H bf16 = 56 KB at 7B, 208 KB at 70B -- latency-bound, no collective on the data path), preceded by ONE
-  64-byte header {go, P, rows, verified context length} that also carries the previous step's rollback
-  (`crop_past_key_values`, SSG:219-221, is a counter write on every rank; each layer's KV lives only on its owner);
-* the last rank runs the final norm + lm_head + argmax and returns the T_d+1 verified token ids (<= 136 B) to
-  rank 0, which runs the greedy acceptance (SSG:186-190);
+  (`exit_query_cache || last draft` = T_d+1 hidden rows, LMU:364-383) travels rank to rank as ONE fixed-size message
+  per hop -- S+2 rows of the engines' message buffer: row 0 a header {go, prompt length, rows, verified context length,
+  draft ids}, rows 1.. the hidden rows -- by point-to-point `send/recv` straight from / into engine memory (RCCL
+  over one xGMI link per hop: (S+2) x H bf16 = 64 KB at 7B, 230 KB at 70B -- latency-bound, no collective on the
+  data path).  NO RANK READS THE HEADER ON THE HOST BEFORE IT HAS ENQUEUED THE STEP: the rollback it carries
+  (`crop_past_key_values`, SSG:219-221: a counter write on every rank; each layer's KV lives only on its owner) is
+  applied by a kernel (`lsk_pipeline_apply`), the launches of the rank's layer range are queued behind the receive,
+  the block is forwarded, and only then does the host look at the header (go / stop, the exact context length) -- its
+  launch overhead overlaps the wait for the message instead of following it;
+* the last rank runs the final norm + lm_head + argmax AND the wavefront-ballot acceptance kernel (SSG:186-190, a
+  drafted EOS ends the draft, SSG:146-148) against the header's draft ids (`lsk_pipeline_tail`) and returns a 96-byte
+  result block {num_matches, num_drafts, next token, context length, emitted tokens} to rank 0;
 * OPTIMISTIC OVERLAP: while the verify block of step k is in flight, rank 0 keeps drafting step k+1
   under the assumption that every draft is accepted and that the bonus token equals its own head's next guess.  If
   that is what the verify returns, step k+1's verify block is ready the moment step k's result arrives; otherwise the
@@ -25,8 +29,10 @@ This module is the MI355X-native form of that partition (SURVEY.md section 8e, B
 
 One sequence is a serial draft -> verify chain, so the pipeline buys capacity (a model beyond one GPU's HBM) and
 hides only what the optimistic guess gets right; independent requests scale as replicas (bench.py reports both).
-All ranks call `generate` collectively.  The stage backend is the `HipEngine` API; tests drive the same protocol over
-gloo with a CPU backend.
+All ranks call `generate` collectively: rank 0 broadcasts (prompt length, speculations, max_steps, eos ids), EVERY rank
+sizes its engine for the whole generation up front, and the ranks agree that all of them could before the first block
+moves (a capacity error surfaces on every rank at once, not as a hang of the others).  The stage backend is the
+`HipEngine` API; tests drive the same protocol over gloo with a CPU backend.
 """
 from __future__ import annotations
 
@@ -39,23 +45,34 @@ import torch.distributed as dist
 
 BUF_STEP = 0
 BUF_BULK = 1
+BUF_MSG = 2         # row 0 = header (int32 words), rows 1.. = the verify block
 _MAX_ROWS = 16
-_HDR = 8            # int64 words of the per-step header
+_MAX_EOS = 8
+_RES_WORDS = 24     # of the result block: num_matches, num_drafts, next token, context length, emitted[17]
+# header words (layerskip_amd/csrc/lsk_accept.h)
+HDR_MAGIC, HDR_GO, HDR_P, HDR_ROWS, HDR_KV, HDR_DRAFTS, HDR_WORDS = 0, 1, 2, 3, 4, 5, 24
+HDR_MAGIC_VALUE = 0x4C534B31
 
 
-def plan_partition(num_layers: int, exit_layer: int, world: int) -> List[Tuple[int, int]]:
-    """Contiguous layer ranges per rank.  Rank 0 gets the early layers (it also pays for the S draft
-    passes over them); the late layers are spread evenly over the other ranks."""
+def plan_partition(num_layers: int, exit_layer: int, world: int, balance: str = "draft") -> List[Tuple[int, int]]:
+    """Contiguous layer ranges per rank.
+    balance = "draft" (default): rank 0 gets exactly the early layers -- it already pays for the S draft passes over
+    them -- and the late layers are spread evenly over the other ranks (shortest verify chain per step);
+    balance = "memory": layers are spread evenly over ALL ranks by count (rank 0 never fewer than `exit_layer`), the
+    capacity split of SURVEY.md 8e: llama2-13B on 2 GPUs = [0, 20) + [20, 40), llama2-70B on 8 = [0, 12) + 7 x 9..10."""
     if world == 1:
         return [(0, num_layers)]
     if not (1 <= exit_layer < num_layers):
         raise ValueError("exit_layer must be in [1, num_layers)")
-    late = num_layers - exit_layer
+    if balance not in ("draft", "memory"):
+        raise ValueError("balance must be 'draft' or 'memory'")
+    first = exit_layer if balance == "draft" else max(exit_layer, -(-num_layers // world))
+    late = num_layers - first
     rest = world - 1
     if late < rest:
         raise ValueError(f"{late} late layers cannot be split over {rest} ranks")
-    out = [(0, exit_layer)]
-    start = exit_layer
+    out = [(0, first)]
+    start = first
     for r in range(rest):
         n = late // rest + (1 if r < late % rest else 0)
         out.append((start, start + n))
@@ -89,27 +106,25 @@ class PipelineSpeculativeDecoder:
         for (a, b), (c, d) in zip(self.partition, self.partition[1:]):
             if b != c:
                 raise ValueError("layer ranges must be contiguous")
-        self._stats = {"steps": 0, "optimistic_attempts": 0, "optimistic_hits": 0, "draft_s": 0.0, "verify_roundtrip_s": 0.0}
+        self._stats = {"steps": 0, "optimistic_attempts": 0, "optimistic_hits": 0, "draft_s": 0.0, "verify_roundtrip_s": 0.0,
+                       "hop_wait_s": 0.0, "hop_enqueue_s": 0.0, "hops": 0}
 
     def stats(self) -> dict:
+        """Rank 0: steps, optimistic attempts / hits, draft and verify-round-trip time per step.  Ranks > 0: per hop, the time
+        the host spent enqueueing the step (receive posted .. block forwarded) and the time it then waited for the message."""
         s = dict(self._stats)
         if s["steps"]:
             s["draft_ms_per_step"] = round(1e3 * s["draft_s"] / s["steps"], 3)
             s["verify_roundtrip_ms_per_step"] = round(1e3 * s["verify_roundtrip_s"] / s["steps"], 3)
-        s.pop("draft_s"), s.pop("verify_roundtrip_s")
+            s["optimistic_hit_rate"] = round(s["optimistic_hits"] / max(1, s["optimistic_attempts"]), 4)
+        if s["hops"]:
+            s["hop_enqueue_ms"] = round(1e3 * s["hop_enqueue_s"] / s["hops"], 3)
+            s["hop_wait_ms"] = round(1e3 * s["hop_wait_s"] / s["hops"], 3)
+        for k in ("draft_s", "verify_roundtrip_s", "hop_wait_s", "hop_enqueue_s"):
+            s.pop(k)
         return s
 
     # ------------------------------------------------------------------ comm helpers
-    def _send_ints(self, values: Sequence[int], dst: int) -> None:
-        t = torch.zeros(max(_HDR, len(values)), dtype=torch.int64)
-        t[: len(values)] = torch.tensor([int(v) for v in values], dtype=torch.int64)
-        dist.send(t.to(self.dev), dst=dst, group=self.group)
-
-    def _recv_ints(self, n: int, src: int) -> List[int]:
-        t = torch.zeros(max(_HDR, n), dtype=torch.int64, device=self.dev)
-        dist.recv(t, src=src, group=self.group)
-        return [int(v) for v in t.tolist()[:n]]
-
     def _rows_out(self, buffer: int, row_base: int, m: int, dst: int) -> None:
         view = self.be.rows_view(buffer, row_base, m)
         dist.send(view if self.direct else view.to(self.dev), dst=dst, group=self.group)
@@ -123,68 +138,124 @@ class PipelineSpeculativeDecoder:
             dist.recv(t, src=src, group=self.group)
             self.be.write_rows(buffer, row_base, t)
 
-    # ------------------------------------------------------------------ the late ranks: serve verify blocks until told to stop
-    def _serve(self) -> None:
+    def _agree(self, prompt_ids, eos_token_ids, max_steps: int, S: int):
+        """Collective set-up: rank 0's (P, S, max_steps, eos ids) reach every rank, every rank sizes its engine for the WHOLE
+        generation (rank 0's optimistic continuation writes up to 2S+2 positions past the verified length; the stop message
+        makes the late ranks run one block on stale rows), and all ranks learn whether all of them could."""
         be = self.be
-        last = self.world - 1
-        while True:
-            go, P, m, kv = self._recv_ints(4, self.rank - 1)
-            if self.rank < last:
-                self._send_ints([go, P, m, kv], self.rank + 1)
-            be.set_kv_len(kv)                      # the rollback of the previous step / the final verified length
-            if not go:
-                return
-            if P > 1:
-                self._rows_in(BUF_BULK, 0, P - 1, self.rank - 1)
-            self._rows_in(BUF_STEP, 0, m, self.rank - 1)
-            if P > 1:
-                be.run_bulk(P - 1, self.lb, self.le)
-            be.run_layers(BUF_STEP, 0, m, P - 1, self.lb, self.le)
-            if self.rank < last:
-                if P > 1:
-                    self._rows_out(BUF_BULK, 0, P - 1, self.rank + 1)
-                self._rows_out(BUF_STEP, 0, m, self.rank + 1)
-            else:
-                self._send_ints(be.run_head(BUF_STEP, 0, m), 0)
+        meta = torch.zeros(4 + _MAX_EOS, dtype=torch.int64)
+        if self.rank == 0:
+            eos = [int(t) for t in eos_token_ids if t is not None and 0 <= int(t) < be.vocab]
+            if len(eos) > _MAX_EOS:
+                raise ValueError(f"{len(eos)} eos token ids; at most {_MAX_EOS}")
+            meta[:4] = torch.tensor([len(prompt_ids), S, max_steps, len(eos)])
+            meta[4:4 + len(eos)] = torch.tensor(eos, dtype=torch.int64)
+        if self.world > 1:
+            meta = meta.to(self.dev)
+            dist.broadcast(meta, src=0, group=self.group)
+            meta = meta.cpu()
+        P, S, max_steps, n_eos = (int(v) for v in meta[:4].tolist())
+        eos = [int(v) for v in meta[4:4 + n_eos].tolist()]
+        err = None
+        try:
+            if S + 1 > _MAX_ROWS:
+                raise ValueError("num_speculations too large for the 16-row verify block")
+            if max_steps < 1 or P < 1:
+                raise ValueError("max_steps and the prompt length must be at least 1")
+            be.ensure_capacity(P + max_steps + 2 * S + 2 + _MAX_ROWS, P)
+            be.reset()
+            be.set_eos(eos)
+        except Exception as exc:          # noqa: BLE001 -- reported on every rank below
+            err = exc
+        if self.world > 1:
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int64, device=self.dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 0:
+                raise RuntimeError(f"pipeline set-up failed on rank {self.rank}: {err}" if err is not None
+                                   else "pipeline set-up failed on another rank (capacity / configuration); nothing was started")
+        elif err is not None:
+            raise err
+        return P, S, max_steps, eos
 
-    # ------------------------------------------------------------------ rank 0: one verify round trip
-    def _verify(self, P: int, m: int, kv: int, row_base: int) -> List[int]:
-        """Late layers + head over step rows [row_base, row_base + m) (and the P-1 prompt rows): locally for the range this
-        rank owns, then through the other ranks."""
+    # ------------------------------------------------------------------ the late ranks: serve verify blocks until told to stop
+    def _serve(self, P0: int, S: int) -> None:
+        be = self.be
+        last = self.rank == self.world - 1
+        bound = 0                       # host-side UPPER bound of the verified context before the step being served
+        p = P0                          # new tokens in front of the block: the prompt on the first step, 1 afterwards
+        while True:
+            t0 = time.perf_counter()
+            if p > 1:
+                self._rows_in(BUF_BULK, 0, p - 1, self.rank - 1)
+            self._rows_in(BUF_MSG, 0, S + 2, self.rank - 1)
+            be.pipeline_apply(bound)                         # the header's rollback, on the device
+            if p > 1:
+                be.run_bulk(p - 1, self.lb, self.le)
+            be.run_layers(BUF_MSG, 1, S + 1, p - 1, self.lb, self.le)
+            if not last:
+                if p > 1:
+                    self._rows_out(BUF_BULK, 0, p - 1, self.rank + 1)
+                self._rows_out(BUF_MSG, 0, S + 2, self.rank + 1)
+            else:
+                res = be.pipeline_tail(S + 1)                # head + argmax + acceptance kernel -> device result block
+                dist.send(res[:_RES_WORDS] if self.direct else res[:_RES_WORDS].to(self.dev), dst=0, group=self.group)
+            t1 = time.perf_counter()
+            # only now the host looks at the header: everything above is already queued behind the receive
+            hdr = be.header()
+            t2 = time.perf_counter()
+            self._stats["hops"] += 1
+            self._stats["hop_enqueue_s"] += t1 - t0
+            self._stats["hop_wait_s"] += t2 - t1
+            if hdr[HDR_MAGIC] != HDR_MAGIC_VALUE:
+                raise RuntimeError(f"rank {self.rank}: message without a header (protocol out of step)")
+            if not hdr[HDR_GO]:
+                be.set_kv_len(hdr[HDR_KV])                   # the final verified length, exactly
+                return
+            if hdr[HDR_P] != p:
+                raise RuntimeError(f"rank {self.rank}: header says {hdr[HDR_P]} new tokens, expected {p}")
+            bound = hdr[HDR_KV] + p + S                      # the next block's rollback cannot exceed this
+            p = 1
+
+    # ------------------------------------------------------------------ rank 0: ship one verify block / fetch its result
+    def _ship(self, P: int, m: int, kv: int, row_base: int):
+        """Rank 0's own late layers (if it owns any) over step rows [row_base, row_base + m) and the prompt rows, then the block
+        into the message buffer.  One rank: the tail (head + acceptance kernel) runs here; otherwise the block leaves."""
         be, E = self.be, self.E
         if self.le > E:
             if P > 1:
                 be.run_bulk(P - 1, E, self.le)
             be.run_layers(BUF_STEP, row_base, m, P - 1, E, self.le)
+        be.pipeline_pack(1, P, row_base, m, kv)
         if self.world == 1:
-            return be.run_head(BUF_STEP, row_base, m)
-        self._send_ints([1, P, m, kv], 1)
+            return be.pipeline_tail(m)
         if P > 1:
             self._rows_out(BUF_BULK, 0, P - 1, 1)
-        self._rows_out(BUF_STEP, row_base, m, 1)
-        return []          # the ids come back later: _collect
+        self._rows_out(BUF_MSG, 0, self._S + 2, 1)
+        return None
 
-    def _collect(self, m: int) -> List[int]:
-        return self._recv_ints(m, self.world - 1)
+    def _result(self, local) -> List[int]:
+        if local is not None:
+            return [int(v) for v in local[:_RES_WORDS].tolist()]
+        t = torch.zeros(_RES_WORDS, dtype=torch.int32, device=self.dev)
+        dist.recv(t, src=self.world - 1, group=self.group)
+        return [int(v) for v in t.tolist()]
 
     # ------------------------------------------------------------------ whole generation (collective)
     def generate(self, prompt_ids: Optional[Sequence[int]], eos_token_ids: Sequence[int], max_steps: int,
                  num_speculations: int) -> PipelineResult:
-        """Rank 0 passes the prompt; other ranks pass None.  Mirrors SSG:32-99 (greedy)."""
-        if num_speculations + 1 > _MAX_ROWS:
-            raise ValueError("num_speculations too large for the 16-row verify block")
-        be, E, S = self.be, self.E, int(num_speculations)
-        be.reset()
+        """Rank 0 passes the prompt and the settings; other ranks' arguments are ignored.  Mirrors SSG:32-99 (greedy)."""
+        be, E = self.be, self.E
+        P0, S, max_steps, eos = self._agree(prompt_ids, eos_token_ids, int(max_steps), int(num_speculations))
+        self._S = S
         if self.rank > 0:
-            self._serve()
+            self._serve(P0, S)
             return PipelineResult([], None, [])
-        eos = [int(t) for t in eos_token_ids]
         out: List[int] = []
         steps: List[Tuple[int, int]] = []
         matches = gens = 0
         cur = [int(t) for t in prompt_ids]
         kv = 0                                     # verified context length (host mirror)
-        cont = None                                # a ready optimistic continuation: {"tokens": [...], "guess": int | None}
+        cont = None                                # a ready optimistic continuation (its rows were moved down to row 0)
         # rows of one block: input + S drafts; a continuation lives in rows S+1 .. 2S+1 (+ one row for its own guess)
         room_cont = 2 * S + 2 <= _MAX_ROWS
         room_chain = 2 * S + 3 <= _MAX_ROWS
@@ -192,32 +263,34 @@ class PipelineSpeculativeDecoder:
             s_eff = max(0, min(S, max_steps - len(out) - 1))
             P = len(cur)
             t0 = time.perf_counter()
-            if cont is not None and s_eff == S:
-                # the rows of this step were drafted while the previous verify was in flight (and moved down to row 0)
-                drafts, guess = cont["tokens"], cont["guess"]
-            else:
+            fresh = not (cont is not None and s_eff == S)
+            want_guess = False
+            if fresh:
                 want_guess = self.optimistic and s_eff == S and room_cont
                 be.draft_block(cur, 0, s_eff + 1, P - 1, E, head_last=want_guess)
+            # ship the block BEFORE looking at the drafts on the host: the drafted-EOS cut (SSG:146-148) and the prefix match are
+            # the acceptance kernel's job on the last rank; the late ranks compute rows the cut drops, harmlessly
+            local = self._ship(P, s_eff + 1, kv, 0)
+            t1 = time.perf_counter()
+            if fresh:
                 toks = be.row_tokens(1, s_eff + (1 if want_guess else 0)) if (s_eff or want_guess) else []
                 drafts, guess = toks[:s_eff], (toks[s_eff] if want_guess else None)
+            else:
+                drafts, guess = cont["tokens"], cont["guess"]
             cont = None
-            td = next((i + 1 for i, t in enumerate(drafts) if t in eos), len(drafts))       # a drafted EOS ends the draft (SSG:146-148)
-            drafts = drafts[:td]
-            m = td + 1
-            t1 = time.perf_counter()
-            verified = self._verify(P, m, kv, 0)
-            attempt = self.world > 1 and guess is not None and td == S and (max_steps - len(out) - (S + 1) - 1) >= S
+            no_eos_drafted = not any(t in eos for t in drafts)
+            attempt = (self.world > 1 and guess is not None and len(drafts) == S and no_eos_drafted
+                       and (max_steps - len(out) - (S + 1) - 1) >= S)
             if attempt:
                 # step k+1, optimistically: input = the guessed bonus token (its embedding already sits in row S+1)
                 be.draft_block(None, S + 1, S + 1, P - 1 + S + 1, E, head_last=room_chain)
                 self._stats["optimistic_attempts"] += 1
-            if self.world > 1:
-                verified = self._collect(m)
+            res = self._result(local)
             t2 = time.perf_counter()
-            n = 0
-            while n < td and drafts[n] == verified[n]:
-                n += 1
-            nxt = verified[n]
+            n, td, nxt = res[0], res[1], res[2]
+            emitted = res[4:4 + n + 1]
+            if emitted != drafts[:n] + [nxt] or td > len(drafts):
+                raise RuntimeError("pipeline result block inconsistent with the drafted tokens")
             kv += P + n
             be.set_kv_len(kv)
             if attempt and n == S and nxt == guess:
@@ -231,13 +304,15 @@ class PipelineSpeculativeDecoder:
             self._stats["steps"] += 1
             self._stats["draft_s"] += t1 - t0
             self._stats["verify_roundtrip_s"] += t2 - t1
-            out.extend(drafts[:n] + [nxt])
+            out.extend(emitted)
             hit = [out.index(e) for e in eos if e in out]
             if hit:
                 out = out[: hit[0]]
                 break
             cur = [nxt]
         if self.world > 1:
-            self._send_ints([0, 0, 0, kv], 1)
+            be.pipeline_pack(0, 1, 0, 1, kv)            # stop message: header only (the final verified length)
+            self._rows_out(BUF_MSG, 0, S + 2, 1)
+            self._result(None)                         # the late ranks answer every message; this one is discarded
         rate = (matches / gens) if gens else None
         return PipelineResult(out, rate, steps)

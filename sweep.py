@@ -9,6 +9,7 @@ differs from the reference's eager path once launch overhead is gone.
 from __future__ import annotations
 
 import csv
+import datetime
 import os
 from dataclasses import dataclass, replace
 
@@ -36,15 +37,16 @@ def main():
     torch.manual_seed(args.seed)
     # the synthetic checkpoint's late-layer damping depends on the exit layer: rebuild per exit layer
     os.makedirs(args.output_dir, exist_ok=True)
-    path = os.path.join(args.output_dir, "sweep.csv")
+    path = os.path.join(args.output_dir, f"sweep_{datetime.datetime.now().strftime('%Y%m%d_%H%M%S')}.csv")      # sweep.py:43-44
     rows = []
     for e in range(sw.exit_layer_first, sw.exit_layer_last + 1, sw.exit_layer_step):
         model, tokenizer = load_model_and_tokenizer(args, syn, e)
         for s in range(sw.num_speculations_first, sw.num_speculations_last + 1, sw.num_speculations_step):
             cfg = replace(gen, exit_layer=e, num_speculations=s, generation_strategy="self_speculative", sample=False)
             m = benchmark(model, tokenizer, b, cfg, syn, args.seed)
-            rows.append({"exit_layer": e, "num_speculations": s, "acceptance_rate": m["acceptance_rate"]["mean"],
-                         "time_per_token": m["time_per_token"]["mean"], "tokens_per_second": m["tokens_per_second"]["mean"]})
+            rows.append({"exit_layer": e, "num_speculations": s, "acceptance_rate": m["acceptance_rate"]["mean"],     # sweep.py:54-61
+                         "total_time": m["total_time"]["mean"], "time_per_token": m["time_per_token"]["mean"],
+                         "tokens_per_second": m["tokens_per_second"]["mean"]})
             print(rows[-1], flush=True)
             with open(path, "w", newline="") as f:             # rewritten after every grid point (sweep.py:62-64)
                 w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))

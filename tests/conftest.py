@@ -15,6 +15,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """tests/test_gpu_struct_parity.py builds one checkpoint per fixture on the CPU (a deterministic CPU generator: up to 13 B
+    parameters, minutes each) and keeps ONE resident: run every test of a fixture back to back instead of every fixture of a
+    test, so each big checkpoint is built once per session."""
+    idx = [i for i, it in enumerate(items) if it.fspath.basename == "test_gpu_struct_parity.py"]
+    if not idx:
+        return
+    block = [items[i] for i in idx]
+    order = {}
+
+    def key(it):
+        name = getattr(getattr(it, "callspec", None), "params", {}).get("name", "")
+        return order.setdefault(name, len(order)) if name else -1
+
+    block.sort(key=key)                     # stable: first-seen fixture order, un-parametrised tests first
+    for i, it in zip(idx, block):
+        items[i] = it
+
+
 def golden_names():
     return sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json"))
 

@@ -20,7 +20,9 @@ class CpuStageBackend:
         self.lb, self.le = layer_range if layer_range is not None else (0, self.num_layers)
         if self.om is None:
             self.om = self._partial_oracle(model)
-        self.buf = {0: torch.zeros(16, self.hidden), 1: torch.zeros(max_rows, self.hidden)}
+        # 0: step rows, 1: prompt rows, 2: the pipeline message (row 0 = header words, rows 1.. = the verify block)
+        self.buf = {0: torch.zeros(16, self.hidden), 1: torch.zeros(max_rows, self.hidden), 2: torch.zeros(17, self.hidden)}
+        self._eos = []
         self.kv = [None] * self.num_layers
         self._kv_len = 0
         self._row_tokens = [0] * 18
@@ -115,6 +117,49 @@ class CpuStageBackend:
                 tok = self.run_head(0, row0 + j, 1)[0]
                 self._row_tokens[row0 + j + 1] = tok
                 self.embed_rows([tok], 0, row0 + j + 1)
+
+    # ---- the message protocol of layerskip_amd/pipeline.py (lsk_pipeline_pack / _apply / _tail, lsk_accept.h's header words)
+    def _hdr(self):
+        return self.buf[2][0].view(torch.int32)
+
+    def set_eos(self, eos):
+        self._eos = [int(t) for t in eos]
+
+    def header(self):
+        return [int(v) for v in self._hdr()[:24].tolist()]
+
+    def pipeline_pack(self, go, prompt_len, src_row, m, kv):
+        hdr = self._hdr()
+        hdr[:24] = 0
+        hdr[0], hdr[1], hdr[2], hdr[3], hdr[4] = 0x4C534B31, 1 if go else 0, prompt_len, m, kv
+        for i in range(m - 1):
+            hdr[5 + i] = self._row_tokens[src_row + 1 + i]
+        if go:
+            self.buf[2][1:1 + m] = self.buf[0][src_row:src_row + m]
+
+    def pipeline_apply(self, kv_bound):
+        hdr = self.header()
+        if hdr[0] == 0x4C534B31:
+            assert hdr[4] <= kv_bound, "the host-side bound must cover the header's context length"
+            self._kv_len = hdr[4]
+
+    def pipeline_tail(self, m):
+        """lsk_pipeline_accept_kernel: drafts and row count from the header, a drafted EOS ends the draft, longest prefix."""
+        hdr = self.header()
+        rows = min(max(hdr[3], 1), 16)
+        verified = self.run_head(2, 1, m)
+        drafts = hdr[5:5 + rows - 1]
+        td = next((i + 1 for i, t in enumerate(drafts) if t in self._eos), len(drafts))
+        n = 0
+        while n < td and drafts[n] == verified[n]:
+            n += 1
+        self._kv_len += hdr[2] + n
+        res = torch.zeros(64, dtype=torch.int32)
+        res[0], res[1], res[2], res[3] = n, td, verified[n], self._kv_len
+        for i in range(n):
+            res[4 + i] = drafts[i]
+        res[4 + n] = verified[n]
+        return res
 
     def row_tokens(self, row0, n):
         return list(self._row_tokens[row0:row0 + n])

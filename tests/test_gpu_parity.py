@@ -412,3 +412,35 @@ def test_engine_follows_weight_changes_on_the_same_model_object(gpu_device):
     assert get_engine(model) is eng and not eng.weights_changed(model)
     assert b.predicted_tokens == rec_b["bf16"]["spec_tokens"]
     assert b.acceptance_rate == rec_b["bf16"]["acceptance_rate"]
+
+
+def test_engine_notices_edits_through_dot_data(gpu_device):
+    """`p.data += delta` (PEFT's default LoRA merge) moves neither a Parameter's address nor its version counter: the sampled
+    content checksum of the fingerprint (lsk_engine_weights_checksum) is what catches it.  After such a merge on the same model
+    object the next generation must come from the merged weights, like the reference's (it reads live weights)."""
+    from conftest import build_struct_model, load_struct
+    from layerskip_amd import GenerationConfig
+    from layerskip_amd.engine import get_engine
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    rec_a, rec_b = load_struct("tiny_gqa"), load_struct("tiny_gqa_spec15")        # same shape, different seeds
+    model = build_struct_model(rec_a, gpu_device)
+    other = build_struct_model(rec_b, gpu_device)
+    strat = HipSelfSpeculativeGenerationStrategy()
+    cfg = GenerationConfig(max_steps=rec_a["max_steps"], exit_layer=rec_a["exit_layer"], num_speculations=rec_a["num_speculations"], sample=False)
+    assert strat.generate_token_ids(model, rec_a["prompt"], rec_a["eos_token_ids"], cfg).predicted_tokens == rec_a["bf16"]["spec_tokens"]
+    eng = get_engine(model)
+    versions = [p._version for p in model.parameters()]
+    ptrs = [p.data_ptr() for p in model.parameters()]
+    with torch.no_grad():
+        for p, q in zip(model.parameters(), other.parameters()):
+            p.data.copy_(q.data)                              # through .data: no version bump, same storage
+    assert versions == [p._version for p in model.parameters()] and ptrs == [p.data_ptr() for p in model.parameters()]
+    assert eng.weights_changed(model)
+    cfg_b = GenerationConfig(max_steps=rec_b["max_steps"], exit_layer=rec_b["exit_layer"], num_speculations=rec_b["num_speculations"], sample=False)
+    b = strat.generate_token_ids(model, rec_b["prompt"], rec_b["eos_token_ids"], cfg_b)
+    assert get_engine(model) is eng and not eng.weights_changed(model)
+    assert b.predicted_tokens == rec_b["bf16"]["spec_tokens"] and b.acceptance_rate == rec_b["bf16"]["acceptance_rate"]
+    # a single-tensor merge (one projection of one layer, `+=` through .data) is seen too
+    with torch.no_grad():
+        model.model.layers[1].mlp.down_proj.weight.data += 0.125
+    assert eng.weights_changed(model)

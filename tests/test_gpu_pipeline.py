@@ -71,3 +71,70 @@ def test_pipeline_of_hip_engines_equals_the_fused_engine(gpu_device, world, over
         assert stats["optimistic_attempts"] >= 3 and stats["optimistic_hits"] == stats["optimistic_attempts"]
     else:
         assert stats["optimistic_attempts"] > stats["optimistic_hits"]
+
+
+def _nccl_worker(rank, world, port, queue):
+    """One rank per DEVICE, backend nccl (= RCCL): rows go straight from / into the engines' message buffers over xGMI."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    import datetime
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(minutes=5))
+    try:
+        from layerskip_amd import synthetic
+        from layerskip_amd.engine import HipEngine
+        from layerskip_amd.pipeline import PipelineSpeculativeDecoder, plan_partition
+        cfg = synthetic.make_config("tiny-gqa")
+        E, S = 3, 6
+        part = plan_partition(cfg.num_hidden_layers, E, world)
+        model = synthetic.build_structured_model(cfg, seed=4, exit_layer=E, override_frac=0.3, layer_range=part[rank], device=dev)
+        eng = HipEngine(model, max_ctx=512, max_prompt=64, layer_range=part[rank])
+        dec = PipelineSpeculativeDecoder(eng, rank, world, part, E)          # comm device = the engine's device: direct send / recv
+        prompt = synthetic.make_struct_prompt(model.struct_program, 19, 2)
+        res = dec.generate(prompt if rank == 0 else None, [cfg.vocab_size], 40, S)
+        stats = [None] * world
+        dist.all_gather_object(stats, dec.stats())
+        if rank == 0:
+            queue.put((res.predicted_tokens, res.acceptance_rate, res.steps, stats))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: one pipeline rank per device over RCCL")
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_pipeline_over_rccl_one_rank_per_gpu(world):
+    """The transport the gloo twins stand in for, the first time a multi-GPU node runs this suite: backend nccl, one rank per
+    device, rows sent straight from the engines' buffers -- token identity with the fused single-GPU engine."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"{world} GPUs needed")
+    from layerskip_amd import GenerationConfig, synthetic
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    if world - 1 > synthetic.make_config("tiny-gqa").num_hidden_layers - 3:
+        pytest.skip("more ranks than late layers in the tiny checkpoint")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tokens, rate, steps, stats = queue.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = synthetic.make_config("tiny-gqa")
+    dev = torch.device("cuda:0")
+    model = synthetic.build_structured_model(cfg, seed=4, exit_layer=3, override_frac=0.3, device=dev)
+    prompt = synthetic.make_struct_prompt(model.struct_program, 19, 2)
+    strat = HipSelfSpeculativeGenerationStrategy()
+    want = strat.generate_token_ids(model, prompt, [cfg.vocab_size], GenerationConfig(max_steps=40, exit_layer=3, num_speculations=6, sample=False))
+    assert tokens == want.predicted_tokens and rate == want.acceptance_rate
+    assert [tuple(s) for s in steps] == [tuple(s) for s in strat.last_steps]
+    assert all(st["hops"] == len(steps) + 1 for st in stats[1:])          # every late rank served every block and the stop message

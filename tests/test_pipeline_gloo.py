@@ -150,8 +150,59 @@ def test_optimistic_overlap_is_output_preserving(world, override_frac, optimisti
         assert stats["optimistic_attempts"] > stats["optimistic_hits"]          # a forced rejection discarded a continuation
 
 
+def _capacity_worker(rank, world, port, queue):
+    """Rank 1's backend cannot hold the generation: the set-up agreement must make EVERY rank raise before any block moves."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from cpu_stage_backend import CpuStageBackend
+        from layerskip_amd import synthetic
+        from layerskip_amd.pipeline import PipelineSpeculativeDecoder, plan_partition
+        cfg = synthetic.make_config("tiny-mha")
+        part = plan_partition(cfg.num_hidden_layers, 2, world)
+        model = synthetic.build_model(cfg, seed=1, exit_layer=2, late_damping=0.05, layer_range=part[rank])
+        be = CpuStageBackend(model, layer_range=part[rank])
+        if rank == 1:
+            def refuse(total_tokens, prompt_len):
+                raise RuntimeError(f"cannot hold {total_tokens} tokens")
+            be.ensure_capacity = refuse
+        dec = PipelineSpeculativeDecoder(be, rank, world, part, 2)
+        try:
+            dec.generate(synthetic.make_prompt(cfg.vocab_size, 21, 3) if rank == 0 else None, [cfg.vocab_size], 18, 4)
+            queue.put((rank, "no error"))
+        except RuntimeError as exc:
+            queue.put((rank, str(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_capacity_error_surfaces_on_every_rank_not_as_a_hang():
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_capacity_worker, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(queue.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "cannot hold" in got[1]
+    assert "another rank" in got[0] and "another rank" in got[2]
+
+
 def test_partition_plan():
     from layerskip_amd.pipeline import plan_partition
+    assert plan_partition(40, 10, 2, balance="memory") == [(0, 20), (20, 40)]            # SURVEY.md 8e: llama2-13B on two GPUs
+    p70 = plan_partition(80, 12, 8, balance="memory")
+    assert p70[0] == (0, 12) and p70[-1][1] == 80 and {b - a for a, b in p70[1:]} <= {9, 10}
     assert plan_partition(32, 8, 1) == [(0, 32)]
     assert plan_partition(40, 10, 2) == [(0, 10), (10, 40)]
     p = plan_partition(80, 12, 8)

@@ -288,9 +288,12 @@ def test_sweep_driver_writes_the_reference_csv(patched, monkeypatch, tmp_path):
                                       "--max_steps", "6", "--exit_layer_first", "3", "--exit_layer_last", "3", "--num_speculations_first", "2",
                                       "--num_speculations_last", "4", "--num_speculations_step", "2", "--output_dir", str(tmp_path)])
     sweep.main()
-    rows = list(csv.DictReader(open(tmp_path / "sweep.csv")))
+    import glob
+    files = glob.glob(str(tmp_path / "sweep_*.csv"))
+    assert len(files) == 1
+    rows = list(csv.DictReader(open(files[0])))
     assert [(r["exit_layer"], r["num_speculations"]) for r in rows] == [("3", "2"), ("3", "4")]
-    assert set(rows[0]) == {"exit_layer", "num_speculations", "acceptance_rate", "time_per_token", "tokens_per_second"}
+    assert list(rows[0]) == ["exit_layer", "num_speculations", "acceptance_rate", "total_time", "time_per_token", "tokens_per_second"]
     assert all(float(r["tokens_per_second"]) > 0 for r in rows)
 
 

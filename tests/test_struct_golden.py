@@ -14,7 +14,7 @@ TINY = [n for n in struct_names() if n.startswith("tiny")]
 def test_every_fixture_records_healthy_margins():
     """What makes these fixtures decisive: the reference's own bf16 run never decided by less than 16 bf16 ulp."""
     names = struct_names()
-    assert {"full1b", "full7b", "full8b", "slice7b", "slice8b", "slice13b", "slice1b", "tiny_mha", "tiny_gqa", "tiny_d64"} <= set(names)
+    assert {"full1b", "full7b", "full8b", "full7b_512", "full13b", "slice70b", "slice7b", "slice8b", "slice13b", "slice1b", "tiny_mha", "tiny_gqa", "tiny_d64"} <= set(names)
     for name in names:
         rec = load_struct(name)
         b = rec["bf16"]

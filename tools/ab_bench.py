@@ -28,6 +28,25 @@ from layerskip_amd import _lib, synthetic  # noqa: E402
 from layerskip_amd.engine import HipEngine  # noqa: E402
 
 
+class ToolEngine(HipEngine):
+    """No weight-change tracking (variant builds of older sources may lack lsk_engine_weights_checksum)."""
+
+    def _weights_fingerprint(self, m):
+        return None
+
+
+def load_variant(path):
+    """_lib.load for a variant build; entry points an OLDER build does not have yet are skipped (the harness only needs the
+    engine lifetime, generate and profile calls)."""
+    import ctypes
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in _lib.PROTOTYPES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = restype, argtypes
+    return lib
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llama2-7B")
@@ -53,8 +72,8 @@ def main():
     for v in args.variants:
         name, spec = v.split("=", 1)
         path, *opts = spec.split(",")
-        _lib._LIBS["bf16"] = _lib.load(os.path.abspath(path))
-        engines[name] = HipEngine(model, max_ctx=args.prompt_len + args.max_steps + S + 16, max_prompt=args.prompt_len)
+        _lib._LIBS["bf16"] = load_variant(os.path.abspath(path))
+        engines[name] = ToolEngine(model, max_ctx=args.prompt_len + args.max_steps + S + 16, max_prompt=args.prompt_len)
         for o in opts:
             k, val = o.split("=")
             engines[name].set_option(int(k), int(val))
