@@ -45,12 +45,6 @@ __device__ __forceinline__ UnitInfo lsk_unit_info(int u, int units, int ntl, int
 }
 
 #define LSK_OOB_OFFSET 0xF0000000u
-#ifndef LSK_RING_EARLY
-#define LSK_RING_EARLY 1
-#endif
-#ifndef LSK_HEAD_DPP
-#define LSK_HEAD_DPP 1
-#endif
 
 template <int ROT>
 __device__ __forceinline__ void lsk_row16_argmax_step(float& v, int& idx) {
@@ -78,14 +72,36 @@ __host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS
 // RMSNorm (if any) and writes the bf16 rows to LDS later, without touching global memory.
 template <int PRO, int MB>
 __device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int steps_c, int tid, elem8 (&xr)[MB], elem8& nw) {
+    if (PRO == PRO_PLAIN) {
+        // EVERY thread loads, from a clamped (always valid) slice: no exec-masked region around the loads.  Inside such a region
+        // hipcc ended the branch with register copies of the last row's value -- an s_waitcnt on 8 of the 12 outstanding loads in
+        // front of the weight ring of every multi-row o_proj / down launch.  A thread beyond a short chunk re-reads the chunk's
+        // last slice; what it loaded is never stored (lsk_store_chunk).
+        const int k0 = c * LSK_KC_ELEMS + min(tid * 8, steps_c * 32 - 8);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) xr[i] = *(const elem8*)(p.x + (size_t)min(i, p.M - 1) * p.ldx + k0);
+        return;
+    }
+    // (the RMSNorm form keeps the guarded loads: its 16-row template sits at the register limit and the branch-free form spills)
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
         const int k0 = c * LSK_KC_ELEMS + e0;
-        if (PRO == PRO_RMS) nw = *(const elem8*)(p.norm_w + k0);
+        nw = *(const elem8*)(p.norm_w + k0);
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             xr[i] = *(const elem8*)(p.x + (size_t)min(i, p.M - 1) * p.ldx + k0);
         }
+    }
+}
+
+// this thread's share of the rows' sums of squares
+template <int MB>
+__device__ __forceinline__ void lsk_accumulate_squares(const elem8 (&xr)[MB], bool in_range, float (&ss)[MB]) {
+    if (in_range) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = e2f(xr[i][j]); ss[i] = fmaf(f, f, ss[i]); }
     }
 }
 
@@ -201,20 +217,15 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
         for (int i = 0; i < MB; ++i) ss[i] = 0.f;
         // RMSNorm statistics need whole rows: walk the K-chunks last-to-first so chunk 0 stays in xr
-        for (int c = nchunks - 1; c >= LSK_RING_EARLY; --c) {
+        for (int c = nchunks - 1; c >= 1; --c) {
             const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
             lsk_load_chunk<PRO, MB>(p, c, steps_c, tid, xr, nw);
-            if (tid * 8 < steps_c * 32) {
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float f = e2f(xr[i][j]); ss[i] = fmaf(f, f, ss[i]); }
-            }
+            lsk_accumulate_squares<MB>(xr, tid * 8 < steps_c * 32, ss);
         }
         // chunk 0 is only REQUESTED here: the weight ring is queued right behind it, so the first HBM round trip of the
         // stream overlaps the round trip of the rows instead of following it (a wave's loads retire in order: the rows
         // arrive first, the statistics below run under the ring's flight time)
-        if (LSK_RING_EARLY) lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
+        lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
     } else {
         lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
     }
@@ -224,12 +235,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
         ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
     }
     if (PRO == PRO_RMS) {
-        if (LSK_RING_EARLY && tid * 8 < cur.steps_c * 32) {
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = e2f(xr[i][j]); ss[i] = fmaf(f, f, ss[i]); }
-        }
+        lsk_accumulate_squares<MB>(xr, tid * 8 < cur.steps_c * 32, ss);
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const float t = wave_sum(ss[i]);
@@ -393,7 +399,6 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                 int idx = n;
                 if (n >= p.N) { v = -INFINITY; idx = 0x7fffffff; }
                 // argmax over the tile's 16 columns, first (lowest) index wins ties like torch.argmax
-#if LSK_HEAD_DPP
                 // row rotations (DPP, a few cycles each) instead of ds_bpermute round trips: the (value, index) maximum with
                 // the lowest-index tie-break is associative and commutative, so after rotations by 8, 4, 2, 1 every lane of
                 // the 16-lane row holds the row's result; rows >= M of a short pass are skipped (i >= M: no lane group has one)
@@ -403,14 +408,6 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
                     lsk_row16_argmax_step<2>(v, idx);
                     lsk_row16_argmax_step<1>(v, idx);
                 }
-#else
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(v, o, 64);
-                    const int oi = __shfl_xor(idx, o, 64);
-                    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-                }
-#endif
                 if (c16 == 0) { best_v[w * 16 + row] = v; best_i[w * 16 + row] = idx; }
             }
         }

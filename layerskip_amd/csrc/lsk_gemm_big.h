@@ -170,20 +170,30 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
 
     const int c16 = lane & 15;
     const int rg = lane >> 4;
+    // Epilogue operands are requested in ONE batch, raw and from clamped (always valid) addresses, and only then consumed: with a
+    // conversion or a lane predicate at each load hipcc waited for every element where it stood (ISA of the round-2 build: 32-64
+    // "global_load_ushort; s_waitcnt vmcnt(0); global_store_short" groups in a row -- a third of a 56 us o_proj / down launch).
     if (EPI == EPI_RESID) {
+        constexpr int MB4 = MT < 4 ? MT : 4;                  // row tiles per batch: 16 loads in flight, 16 registers
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int n = (T0 + nt) * 16 + c16;
+            const int nc = min(n, p.N - 1);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mb = 0; mb < MT; mb += MB4) {
+                elem_t hres[MB4][4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + mt * 16 + rg * 4 + i;
-                    if (row < p.M && n < p.N) {
-                        elem_t* hp = p.h + (size_t)row * p.ldh + n;
-                        *hp = f2e(e2f(*hp) + rnd_e(acc[mt][nt][i]));
+                for (int mt = 0; mt < MB4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hres[mt][i] = p.h[(size_t)min(m0 + (mb + mt) * 16 + rg * 4 + i, p.M - 1) * p.ldh + nc];
+#pragma unroll
+                for (int mt = 0; mt < MB4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = m0 + (mb + mt) * 16 + rg * 4 + i;
+                        if (row < p.M && n < p.N) p.h[(size_t)row * p.ldh + n] = f2e(e2f(hres[mt][i]) + rnd_e(acc[mb + mt][nt][i]));
                     }
-                }
+            }
         }
     } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
@@ -216,8 +226,22 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
             const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
             const int head = TT / tph;
             const int tt = TT - head * tph;
+            const int j = tt * 8 + (c16 & 7);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                // this row tile's operands in one batch (cos, sin, KV page of the 4 rows of this lane), then the arithmetic
+                elem_t cs_raw[4], sn_raw[4];
+                int pg[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pos = base_pos + min(m0 + mt * 16 + rg * 4 + i, p.M - 1);
+                    cs_raw[i] = (elem_t)0.0f; sn_raw[i] = (elem_t)0.0f; pg[i] = 0;
+                    if (kind != 2) {
+                        cs_raw[i] = p.rope_cos[(size_t)pos * (hd >> 1) + j];
+                        sn_raw[i] = p.rope_sin[(size_t)pos * (hd >> 1) + j];
+                    }
+                    if (kind != 0) pg[i] = p.block_table[pos / p.page_size];
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = m0 + mt * 16 + rg * 4 + i;
@@ -226,9 +250,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
                     int feat;
                     if (kind != 2) {
                         const float partner = row_xor8(v);
-                        const int j = tt * 8 + (c16 & 7);
-                        const float cs = e2f(p.rope_cos[(size_t)pos * (hd >> 1) + j]);
-                        const float sn = e2f(p.rope_sin[(size_t)pos * (hd >> 1) + j]);
+                        const float cs = e2f(cs_raw[i]);
+                        const float sn = e2f(sn_raw[i]);
                         const float a = rnd_e(v * cs);
                         const float b = rnd_e((c16 < 8 ? -partner : partner) * sn);
                         v = rnd_e(a + b);
@@ -240,14 +263,14 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
                         if (kind == 0) {
                             p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2e(v);
                         } else {
-                            const int page = p.block_table[pos / p.page_size];
                             const int slot = pos % p.page_size;
-                            const size_t hb = ((size_t)page * p.n_kv + head) * p.page_size * hd;
+                            const size_t hb = ((size_t)pg[i] * p.n_kv + head) * p.page_size * hd;
                             if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2e(v);        // K page  [slot][d]
                             else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2e(v);         // V^T page [d][slot]
                         }
                     }
                 }
+            }
         }
     }
 }

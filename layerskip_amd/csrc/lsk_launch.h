@@ -7,9 +7,8 @@
 #include "lsk_gemm.h"
 
 static const size_t kMaxGemmLds = 160 * 1024;
-#ifndef LSK_MB_MID
-#define LSK_MB_MID 8              // rows of the middle template of the skinny projection kernel (1 | LSK_MB_MID | 16)
-#endif
+#define LSK_MB_MID 8              // rows of the middle template of the skinny projection kernel (1 | 8 | 16); a 7-row middle
+                                  // template for 6 speculations measured no faster (profiles/r03_kernel_experiments.md)
 
 template <int PRO, int EPI>
 static int set_gemm_attr() {

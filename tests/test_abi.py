@@ -109,3 +109,29 @@ def test_error_messages_come_from_the_library_that_failed():
         _lib.check(1, a)
     with pytest.raises(_lib.LskError, match="n_rows=-1"):
         _lib.check(1, b)
+
+
+def test_no_kernel_spills_to_scratch():
+    """Every kernel of the product library stays in registers (hipcc -Rpass-analysis=kernel-resource-usage: ScratchSize 0).  A spill
+    changes no result, only the speed: the 16-row templates of the skinny projection kernel sit at the 256-register limit and an
+    innocent-looking edit of the prologue pushed them into scratch (llama2-13B verify passes 30 % slower) -- no parity test sees that."""
+    import re
+    import subprocess
+    import tempfile
+    from layerskip_amd import build
+    csrc = os.path.join(ROOT, "layerskip_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(td, "x.so")] + [os.path.join(csrc, s) for s in build.SOURCES]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", proc.stderr)[1:]
+    assert len(blocks) >= 40
+    spilled = []
+    for b in blocks:
+        name = b.split("\n")[0].strip().split()[0]
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b)
+        assert m, name
+        if int(m.group(1)) != 0:
+            spilled.append((name, int(m.group(1))))
+    assert not spilled, spilled

@@ -99,6 +99,23 @@ def main():
             dt = time.perf_counter() - t0
             tps[n].append(toks / dt)
             info[n] = {"crc": crc, "acceptance": round(m / max(1, d), 4), "steps": len(steps)}
+    # the prompt prefill alone (511 rows through every layer, MFMA-tiled kernels): best of 5, and a checksum of the rows
+    prefill = {}
+    from layerskip_amd.engine import BUF_BULK
+    for n, eng in engines.items():
+        rows = args.prompt_len - 1
+        best = 1e9
+        for _ in range(5):
+            eng.reset()
+            eng.embed_rows(prompts[0][:rows], BUF_BULK, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.run_bulk(rows, 0, eng.num_layers)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        crc = zlib.crc32(eng.read_rows(BUF_BULK, 0, rows).view(torch.int16).cpu().numpy().tobytes())
+        eng.reset()
+        prefill[n] = {"prefill_ms": round(1e3 * best, 3), "prefill_rows_crc": crc}
     results = []
     for n, eng in engines.items():
         eng.set_profile(True)
@@ -108,13 +125,13 @@ def main():
         eng.set_profile(False)
         kern = {f"{row['kernel']}{'M' if row['rows'] != '1' else '1'}": round(1e3 * row["ms"] / row["launches"], 2) for row in table}
         results.append({"variant": n, "tok_s_median": round(statistics.median(tps[n]), 1), "tok_s_best": round(max(tps[n]), 1),
-                        "rounds": [round(x, 1) for x in tps[n]], **info[n], "kernels_us": kern})
+                        "rounds": [round(x, 1) for x in tps[n]], **info[n], **prefill[n], "kernels_us": kern})
     for res in results:
         print(json.dumps(res), flush=True)
     keys = list(results[0]["kernels_us"].keys())
-    print(f"{'variant':24s} {'tok/s':>8s} {'best':>8s} {'acc':>6s} {'crc':>10s} " + " ".join(f"{k:>9s}" for k in keys))
+    print(f"{'variant':24s} {'tok/s':>8s} {'best':>8s} {'acc':>6s} {'crc':>10s} {'prefill':>8s} " + " ".join(f"{k:>9s}" for k in keys))
     for res in results:
-        print(f"{res['variant']:24s} {res['tok_s_median']:8.1f} {res['tok_s_best']:8.1f} {res['acceptance']:6.3f} {res['crc']:10d} "
+        print(f"{res['variant']:24s} {res['tok_s_median']:8.1f} {res['tok_s_best']:8.1f} {res['acceptance']:6.3f} {res['crc']:10d} {res['prefill_ms']:8.3f} "
               + " ".join(f"{res['kernels_us'].get(k, 0):9.2f}" for k in keys))
     if args.out:
         with open(args.out, "w") as f:
