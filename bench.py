@@ -275,7 +275,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         avg_ms = ms / launches
         achieved = by / (ms * 1e-3) / 1e9
         traffic, source = None, None
-        for cand in ("r02_pmc_gateup.json", "r01_pmc_gateup.json"):
+        for cand in ("r03_pmc_gateup.json", "r02_pmc_gateup.json", "r01_pmc_gateup.json"):
             pmc = os.path.join(ROOT, "profiles", cand)
             if args.model == "llama2-7B" and os.path.exists(pmc):
                 # HBM bytes per launch need the PMC passes (rocprofv3 --pmc, separate runs): not collectable inside this run

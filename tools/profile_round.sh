@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-gpu-reference --no-sampled"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-gpu-reference --no-sampled --no-operating-points"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o stats -- $BENCH --steps 2 --warmup 1 > "$OUT/stats_bench.log" 2>&1
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_7B_spec.csv"
 SHORT="$BENCH --steps 1 --warmup 0 --max-steps 48"
@@ -18,4 +18,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_A
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $pass -d /tmp/prof_pmc -o pmc -- $SHORT > "$OUT/pmc_$tag.log" 2>&1
   python $REPO/tools/pmc_summary.py /tmp/prof_pmc "$OUT/pmc_$tag.csv" >> "$OUT/pmc_$tag.log" 2>&1
 done
+python $REPO/tools/pmc_gateup_json.py "$OUT" "$OUT/pmc_gateup.json" "$TAG" >> "$OUT/pmc_FETCH_SIZE.log" 2>&1
 ls -la "$OUT"
