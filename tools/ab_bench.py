@@ -2,7 +2,7 @@
 
     python tools/ab_bench.py [--model llama2-7B] [--rounds 3] [--max-steps 512] [--prompt-len 512] name=path.so[,OPT=VALUE...] ...
 
-(`,OPT=VALUE`: lsk_engine_set_option pairs applied to that variant's engine, e.g. new_nocombine=build/variants/new.so,8=0.)
+(`,OPT=VALUE`: lsk_engine_set_option pairs applied to that variant's engine, e.g. graph=build/variants/new.so,7=1 (LSK_OPT_GRAPH_STEPS).)
 
 Every variant gets its own HipEngine over the SAME model object (its own packed weights, KV pool and workspace), the
 variants take turns generating the same prompts, and per variant the script prints tokens/s (median and best of the rounds),
