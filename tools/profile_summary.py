@@ -1,0 +1,76 @@
+"""One table per round from the artefacts of tools/profile_round.sh (CPU, no GPU needed):
+
+    python tools/profile_summary.py r03        # reads profiles/r03_kernel_stats_7B_spec.csv, r03_pmc_hbm_traffic.csv, r03_pmc_sq_counters.csv
+                                               # writes profiles/r03_profile_summary.md and pivots the SQ counters in place
+
+Per engine kernel: launches and average duration (rocprofv3 --kernel-trace --stats), HBM read bytes per launch (FETCH_SIZE x 2, the
+gfx950 correction of MI355X_MICROARCH.md) and write KB per launch (separate --pmc passes), and the SQ fractions: waves parked
+(SQ_WAIT_ANY / SQ_WAVE_CYCLES), MFMA busy cycles per wave quad-cycle (SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAVE_CYCLES, the measure of the round-2 file: ~1 = the
+matrix pipe is the bottleneck, ~0.1 = weight streaming), LDS bank conflicts."""
+import csv
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    prof = os.path.join(ROOT, "profiles")
+    stats = {}
+    for r in csv.DictReader(open(os.path.join(prof, f"{tag}_kernel_stats_7B_spec.csv"))):
+        if "lsk_" in r["Name"]:
+            stats[r["Name"][:120]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+    fetch, write = {}, {}
+    for r in csv.DictReader(open(os.path.join(prof, f"{tag}_pmc_hbm_traffic.csv"))):
+        (fetch if r["counter"] == "FETCH_SIZE" else write)[r["kernel"]] = float(r["mean"])
+    sq_path = os.path.join(prof, f"{tag}_pmc_sq_counters.csv")
+    rows = list(csv.DictReader(open(sq_path)))
+    sq = defaultdict(dict)
+    if rows and "counter" in rows[0]:
+        launches = {}
+        for r in rows:
+            sq[r["kernel"]][r["counter"]] = float(r["mean"])
+            launches[r["kernel"]] = int(r["launches"])
+        names = ["SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY",
+                 "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"]
+        with open(sq_path, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "launches"] + names + ["wait_any_frac", "lds_conflict_frac", "mfma_busy_per_wave_cycle"])
+            for k in sorted(sq):
+                c = sq[k]
+                w.writerow([k, launches[k]] + [f"{c.get(n, 0.0):.1f}" for n in names] + [
+                    f"{c.get('SQ_WAIT_ANY', 0) / max(1.0, c.get('SQ_WAVE_CYCLES', 1)):.3f}",
+                    f"{c.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, c.get('SQ_LDS_IDX_ACTIVE', 1)):.3f}",
+                    f"{c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1.0, c.get('SQ_WAVE_CYCLES', 1)):.4f}"])
+    else:
+        for r in rows:
+            sq[r["kernel"]] = {k: float(v) for k, v in r.items() if k not in ("kernel",)}
+    out = [f"# {tag}: per-kernel profile of the benchmark command (llama2-7B shape, E=8, S=6, 512/512, one MI355X)", "",
+           "`rocprofv3 --kernel-trace --stats` of `bench.py --steps 2 --warmup 1` (durations) and separate `--pmc` passes of a 48-token generation",
+           "(`tools/profile_round.sh`); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md.  Peaks: HBM 8.0 TB/s, bf16 MFMA 2.5 PF.", "",
+           "| kernel | launches | avg us | % of GPU time | HBM read MB / launch | GB/s (read / avg) | write KB / launch | waves parked | MFMA busy / wave cycle | LDS conflict |",
+           "|---|---|---|---|---|---|---|---|---|---|"]
+    for name, (calls, us, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
+        f = fetch.get(name)
+        c = sq.get(name, {})
+        wave = c.get("SQ_WAVE_CYCLES", 0.0)
+        parked = c.get("SQ_WAIT_ANY", 0.0) / wave if wave else (c.get("wait_any_frac") if c else None)
+        mfma = (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / wave) if wave else c.get("mfma_busy_per_wave_cycle")
+        lds = (c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else c.get("lds_conflict_frac", 0.0)
+        mb = f * 1024 * 2 / 1e6 if f is not None else None
+        out.append("| `%s` | %d | %.2f | %.2f | %s | %s | %s | %s | %s | %s |" % (
+            name.replace("void ", "")[:70], calls, us, pct, "%.2f" % mb if mb is not None else "-",
+            "%.0f" % (mb / us * 1e3) if mb is not None else "-", "%.1f" % write[name] if name in write else "-",
+            "%.2f" % parked if parked is not None else "-", "%.3f" % mfma if mfma is not None else "-", "%.3f" % (lds or 0.0)))
+    out += ["", "Reading: the decode projections (`lsk_gemm_kernel<PRO, EPI, rows>`) fetch their packed weights ONCE (HBM read = algorithmic bytes to the",
+            "third digit) at 0.09-0.10 MFMA busy cycles per wave cycle -- weight streaming, as a <= 16-row product must be; a third of the wave cycles are",
+            "parked on `s_waitcnt` / barriers and most of the rest are issue stalls behind the in-order weight ring (SQ_WAIT_INST_ANY), i.e. the kernels wait on",
+            "HBM, not on arithmetic.  The prefill kernels (`lsk_gemm_big_kernel`) are the MFMA-shaped part (0.8-1.0)."]
+    open(os.path.join(prof, f"{tag}_profile_summary.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out[:24]))
+
+
+if __name__ == "__main__":
+    main()
