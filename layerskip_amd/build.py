@@ -26,6 +26,13 @@ def _inputs():
     return files
 
 
+# The compile flags of every build of the extension (the libraries, the measurement variants of tools/, the resource checks of
+# tests/test_abi.py).  -amdgpu-kernarg-preload-count: the first 14 argument dwords of every kernel are in SGPRs when a wave starts
+# (GemmHot in csrc/lsk_gemm.h says what rides there and why); the code object keeps a compatibility prologue for firmware without it.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+               "-mllvm", "-amdgpu-kernarg-preload-count=14"]
+
+
 def _stale(lib: str) -> bool:
     if not os.path.exists(lib):
         return True
@@ -35,8 +42,7 @@ def _stale(lib: str) -> bool:
 
 def _compile(lib: str, defines, verbose: bool, sources=None) -> None:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function"] + list(defines) + ["-o", lib] + [os.path.join(CSRC, s) for s in (sources or SOURCES)]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-fPIC", "-shared"] + list(defines) + ["-o", lib] + [os.path.join(CSRC, s) for s in (sources or SOURCES)]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)

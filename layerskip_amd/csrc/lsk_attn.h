@@ -54,6 +54,21 @@ struct AttnSplitParams {
     int n_pages;            // page-workgroups per head column in this launch
     int heads_per_wg;       // HW: query heads (of one KV head) per workgroup, HW * M <= 16, HW divides group
     int inv_m;              // ceil(256 / M): i / M == (i * inv_m) >> 8 for every row index i < 16
+    LSK_TRACE_FIELD
+};
+
+// What a workgroup needs before it can request Q, K and V rides as explicit kernel arguments in front of the block (preloaded
+// into SGPRs at wave start, see GemmHot in lsk_gemm.h): 14 dwords.
+struct AttnHot {
+    const elem_t* q;
+    const elem_t* kpool;
+    const elem_t* vpool;
+    const int* block_table;
+    const int* kv_len;
+    int ldq;
+    int geom;               // n_kv | group << 16
+    int rows;               // M | heads_per_wg << 8 | inv_m << 16
+    int pos_off;
 };
 
 #define LSK_ATTN_LDS_PBUF 0
@@ -71,11 +86,13 @@ struct AttnCombineParams {
 };
 
 template <int HD>
-__device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const int col, const int page_l, unsigned char* lds) {
+__device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplitParams& p, const int col, const int page_l, unsigned char* lds) {
     constexpr int KS = HD / 32;              // k-steps of QK^T
     constexpr int DT = HD / 16;              // output column tiles of PV
     constexpr int PSTRIDE = HD + 2;
     constexpr int PB_STRIDE = 80;            // bytes per P row in LDS: 32 bf16 + 16 B pad
+    LSK_TRACE_DECL;
+    LSK_TRACE_POINT(0);
     unsigned char* pbuf = lds + LSK_ATTN_LDS_PBUF;           // [4 waves][16][80 B]
     float* sm = (float*)(lds + LSK_ATTN_LDS_SM);              // [4 waves][16][HD + 2]
     int* s_last_p = (int*)(lds + LSK_ATTN_LDS_SM + LSK_ATTN_WAVES * 16 * PSTRIDE * 4);
@@ -85,34 +102,34 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15;
     const int g = lane >> 4;
-    const int M = p.M;
-    const int HW = p.heads_per_wg;           // query heads of ONE KV head served by this workgroup: HW * M <= 16 rows
+    const int M = hp.rows & 0xff;
+    const int HW = (hp.rows >> 8) & 0xff;    // query heads of ONE KV head served by this workgroup: HW * M <= 16 rows
+    const int inv_m = hp.rows >> 16;         // ceil(256 / M): i / M == (i * inv_m) >> 8 for every row index i < 16
+    const int n_kv = hp.geom & 0xffff;
     const int head0 = col * HW;              // first query head
-    const int kvh = head0 / p.group;
+    const int kvh = head0 / (hp.geom >> 16);
     const int n_rows = HW * M;               // MFMA row i = (head head0 + i / M, verify row i % M)
     const int key0 = page_l * LSK_ATTN_PAGE;
     const bool fused = p.counters != nullptr;
     // ---- every load of this wave up front ----
-    // the two device scalars first, in ONE scalar-load clause (pinned: hipcc otherwise sinks the block-table read below the
-    // early return, which put a third dependent scalar round trip in front of the K / V requests of a ~5 us kernel)
-    // (the kernel arguments the address arithmetic needs ride along, instead of being read lazily in a clause of their own;
-    // nothing with side effects may stand BEFORE the two reads: hipcc then no longer proves them clobber-free and turns the
-    // scalar loads into vector loads)
-    const int page = p.block_table[page_l];
-    const int kv_now = *p.kv_len;
-    asm volatile("" : : "s"(page), "s"(kv_now), "s"(p.q), "s"(p.ldq), "s"(p.kpool), "s"(p.vpool), "s"(p.n_kv), "s"(p.group), "s"(p.M),
-                 "s"(p.pos_off), "s"(p.heads_per_wg), "s"(p.inv_m), "s"(p.counters));
-    const int base_pos = kv_now + p.pos_off;
+    // the two device scalars first, in ONE scalar-load clause; their pointers (like every argument the address arithmetic below
+    // needs) are preloaded kernel arguments, so this is the FIRST scalar round trip of the wave, not the second.  (Pinned: hipcc
+    // otherwise sinks the block-table read below the early return; nothing with side effects may stand BEFORE the two reads:
+    // hipcc then no longer proves them clobber-free and turns the scalar loads into vector loads.)
+    const int page = hp.block_table[page_l];
+    const int kv_now = *hp.kv_len;
+    asm volatile("" : : "s"(page), "s"(kv_now));
+    const int base_pos = kv_now + hp.pos_off;
     const int qi = min(c16, n_rows - 1);
-    const int qh = (qi * p.inv_m) >> 8;
-    const elem_t* qp = p.q + (size_t)(qi - qh * M) * p.ldq + (size_t)(head0 + qh) * HD + g * 8;
+    const int qh = (qi * inv_m) >> 8;
+    const elem_t* qp = hp.q + (size_t)(qi - qh * M) * hp.ldq + (size_t)(head0 + qh) * HD + g * 8;
     elem8 kb[2][KS], vb[DT], qa[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qa[ks] = *(const elem8*)(qp + ks * 32);
     if (key0 > base_pos + M - 1 && !fused) return;     // page entirely in the future of every row
-    const size_t head_base = ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD;
-    const elem_t* kp = p.kpool + head_base + (size_t)(w * 32 + c16) * HD + g * 8;
-    const elem_t* vp = p.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + w * 32 + g * 8;
+    const size_t head_base = ((size_t)page * n_kv + kvh) * LSK_ATTN_PAGE * HD;
+    const elem_t* kp = hp.kpool + head_base + (size_t)(w * 32 + c16) * HD + g * 8;
+    const elem_t* vp = hp.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + w * 32 + g * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         kb[0][ks] = *(const elem8*)(kp + ks * 32);
@@ -120,9 +137,11 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
+    LSK_TRACE_POINT(1);                                           // every load requested
     // Slots beyond the last key any row can see were never written: the pool is caller-owned memory and may hold
     // anything there, NaN / Inf bit patterns included.  K is harmless (masked scores are SELECTED away, never
     // multiplied), V is not (P = 0 times NaN): zero those V elements.  Only the last page in reach has any.
+    // (Kept HERE, right behind the requests: moved behind the softmax, hipcc sinks the V loads with it, below QK^T.)
     {
         const int nvalid = base_pos + M - (key0 + w * 32 + g * 8);       // valid keys of this lane's run of 8
         if (nvalid < 8) {
@@ -141,13 +160,14 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
         s0 = LSK_MFMA_16x16x32(qa[ks], kb[0][ks], s0, 0, 0, 0);
         s1 = LSK_MFMA_16x16x32(qa[ks], kb[1][ks], s1, 0, 0, 0);
     }
+    LSK_TRACE_POINT(2);                                           // Q and K arrived, S issued
     const int keyA = key0 + w * 32 + c16;    // key of s0's column; s1's is keyA + 16
     float mrow[4], lrow[4];
     unsigned char* pw = pbuf + w * 16 * PB_STRIDE;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = g * 4 + r;
-        const int ih = (i * p.inv_m) >> 8;
+        const int ih = (i * inv_m) >> 8;
         const int lim = base_pos + (i - ih * M);     // last visible key of this row
         const bool ok0 = (i < n_rows) && (keyA <= lim);
         const bool ok1 = (i < n_rows) && (keyA + 16 <= lim);
@@ -185,6 +205,7 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
         }
     }
     __syncthreads();
+    LSK_TRACE_POINT(3);                                           // O = P V of the 4 waves in LDS
     // ---- merge the 4 waves (fixed order) into the page partial of each (head, row) ----
     for (int e = tid; e < n_rows * PSTRIDE; e += LSK_ATTN_THREADS) {
         const int i = e / PSTRIDE;
@@ -203,12 +224,13 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
                 v += src[d] * __builtin_amdgcn_exp2f(src[HD] - m);      // d == HD + 1: the running sum l
             }
         }
-        const int ih = (i * p.inv_m) >> 8;
+        const int ih = (i * inv_m) >> 8;
         float* dstp = p.part + (((size_t)(head0 + ih) * p.max_pages + page_l) * LSK_ROWS + (i - ih * M)) * PSTRIDE + d;
         if (fused) __hip_atomic_store(dstp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
         else *dstp = v;
     }
-    if (!fused) return;
+    if (!fused) { LSK_TRACE_FLUSH(p, col * p.n_pages + page_l); return; }
+    LSK_TRACE_POINT(4);                                           // partial stores issued
     // ---- in-launch combine by the LAST page-workgroup of this head column to arrive -------------------------
     // Publish = write-through (sc1) partial stores, drained by EVERY storing wave (s_waitcnt vmcnt(0) + barrier), then ONE
     // relaxed agent-scope ticket; the last arriver reads all partials with sc1 loads (L1-bypassing) and combines them in
@@ -220,16 +242,18 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
     // two-kernel form (LSK_OPT_FUSED_ATTN = 0) as the gate for any toolchain change.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    LSK_TRACE_POINT(5);                                           // partial stores written through
     if (tid == 0) {
         const int ticket = __hip_atomic_fetch_add(p.counters + col, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_last_p = (ticket == p.n_pages - 1);
     }
     __syncthreads();
-    if (!*s_last_p) return;
+    LSK_TRACE_POINT(6);                                           // ticket returned
+    if (!*s_last_p) { LSK_TRACE_FLUSH(p, col * p.n_pages + page_l); return; }
     for (int e = tid; e < n_rows * (HD / 2); e += LSK_ATTN_THREADS) {
         const int i = e / (HD / 2);
         const int d = (e - i * (HD / 2)) * 2;          // two adjacent features per thread: one 32-bit store
-        const int ih = (i * p.inv_m) >> 8;
+        const int ih = (i * inv_m) >> 8;
         const int r = i - ih * M;
         const int head = head0 + ih;
         const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
@@ -268,13 +292,26 @@ __device__ __forceinline__ void lsk_attn_body(const AttnSplitParams& p, const in
         *(unsigned*)(p.out + (size_t)r * p.ldo + head * HD + d) = packed;
     }
     if (tid == 0) __hip_atomic_store(p.counters + col, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LSK_TRACE
+    LSK_TRACE_POINT(7);                                           // combined output stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LSK_TRACE_POINT(8);
+    lsk_tr[9] = 1;                                                // this workgroup was the head column's last arriver
+    LSK_TRACE_FLUSH(p, col * p.n_pages + page_l);
+#endif
 }
 
 template <int HD>
-__global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const AttnSplitParams p) {
+__global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const elem_t* q, const elem_t* kpool, const elem_t* vpool,
+                                                                           const int* block_table, const int* kv_len, int ldq, int geom,
+                                                                           int rows, int pos_off, const AttnSplitParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[lsk_attn_lds_bytes<HD>()];
-    lsk_attn_body<HD>(p, blockIdx.x, blockIdx.y, lds);
+    const AttnHot hp{q, kpool, vpool, block_table, kv_len, ldq, geom, rows, pos_off};
+    lsk_attn_body<HD>(hp, p, blockIdx.x, blockIdx.y, lds);
 }
+// the explicit-argument list of a launch, from the block
+#define LSK_ATTN_HOT_ARGS(sp) (sp).q, (sp).kpool, (sp).vpool, (sp).block_table, (sp).kv_len, (sp).ldq, ((sp).n_kv | ((sp).group << 16)), \
+                              ((sp).M | ((sp).heads_per_wg << 8) | ((sp).inv_m << 16)), (sp).pos_off, (sp)
 
 template <int HD>
 __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineParams p) {

@@ -79,6 +79,36 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// ---- in-kernel timeline (measurement builds only: tools/kernel_timeline.py compiles the engine with -DLSK_TRACE) ----------
+// Every workgroup of the decode kernels stamps the 100 MHz realtime counter at a few points of its life and writes the stamps,
+// with the XCD / CU it ran on, to a host-provided buffer at its very end.  Without -DLSK_TRACE the macros expand to nothing and
+// the parameter blocks have no extra field: the default build's device code is unchanged.
+#ifdef LSK_TRACE
+#define LSK_TRACE_WORDS 12
+#ifndef LSK_TRACE_TID
+#define LSK_TRACE_TID 0           // the thread (i.e. the wave) whose stamps are kept
+#endif
+#define LSK_TRACE_MAX_WGS 2048
+struct LskTrace { unsigned long long* buf; int seq; };
+#define LSK_TRACE_FIELD LskTrace trace;
+#define LSK_TRACE_DECL unsigned long long lsk_tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define LSK_TRACE_POINT(k) do { __builtin_amdgcn_sched_barrier(0); lsk_tr[k] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LSK_TRACE_FLUSH(p, wg) do { \
+        if (threadIdx.x == LSK_TRACE_TID && (p).trace.buf != nullptr && (wg) < LSK_TRACE_MAX_WGS) { \
+            unsigned hw_id, xcc_id; \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id)); \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id)); \
+            unsigned long long* lsk_td = (p).trace.buf + ((size_t)(p).trace.seq * LSK_TRACE_MAX_WGS + (wg)) * LSK_TRACE_WORDS; \
+            for (int lsk_k = 0; lsk_k < 10; ++lsk_k) lsk_td[lsk_k] = lsk_tr[lsk_k]; \
+            lsk_td[10] = hw_id; lsk_td[11] = xcc_id; \
+        } } while (0)
+#else
+#define LSK_TRACE_FIELD
+#define LSK_TRACE_DECL
+#define LSK_TRACE_POINT(k)
+#define LSK_TRACE_FLUSH(p, wg)
+#endif
+
 // ---- projection (skinny GEMM) -----------------------------------------------------------------
 enum { PRO_PLAIN = 0, PRO_RMS = 1 };
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_HEAD = 4 };
@@ -122,6 +152,7 @@ struct GemmParams {
     int ld_logits;
     float* part_val;        // [grid][16]
     int* part_idx;          // [grid][16]
+    LSK_TRACE_FIELD
 };
 
 struct StepState {

@@ -379,14 +379,17 @@ static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     int pages = 0;
     LSK_TRY(attn_params(e, q, out, kpool, vpool, m, pos_off, sp, pages));
     const dim3 grid(c.n_heads / sp.heads_per_wg, pages), block(LSK_ATTN_THREADS);
+#ifdef LSK_TRACE
+    sp.trace = lsk_trace_next(1, 0, m, (int)(grid.x * grid.y));
+#endif
     hipEvent_t ea = nullptr, eb = nullptr;
     // algorithmic bytes: K and V of every key in reach, once (GQA: each KV head once)
     LSK_TRY(profile_pair(e, LSK_PROF_ATTN, m, 2.0 * 2.0 * c.n_kv_heads * hd * (double)(e->kv_len_host + pos_off + m), &ea, &eb));
     if (ea != nullptr) {
-        if (hd == 128) hipExtLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, ea, eb, 0, sp);
-        else hipExtLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, ea, eb, 0, sp);
-    } else if (hd == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, sp);
-    else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, sp);
+        if (hd == 128) hipExtLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, ea, eb, 0, LSK_ATTN_HOT_ARGS(sp));
+        else hipExtLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, ea, eb, 0, LSK_ATTN_HOT_ARGS(sp));
+    } else if (hd == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, LSK_ATTN_HOT_ARGS(sp));
+    else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, LSK_ATTN_HOT_ARGS(sp));
     HIP_OK(hipGetLastError());
     if (e->fused_attn) return 0;
     AttnCombineParams cp{};
@@ -753,3 +756,16 @@ extern "C" int lsk_engine_get_profile(lsk_engine* e, float* total_ms, int32_t* l
     return 0;
 }
 
+#ifdef LSK_TRACE
+// measurement builds only (not in include/layerskip_hip.h): arm / read the in-kernel timeline, see lsk_common.h
+extern "C" int lsk_trace_begin(void* buf, int cap_launches, int skip_launches) {
+    g_trace_buf = (unsigned long long*)buf; g_trace_cap = cap_launches; g_trace_seq = 0; g_trace_skip = skip_launches;
+    return 0;
+}
+extern "C" int lsk_trace_end(int* tags_out) {
+    const int n = g_trace_seq;
+    if (tags_out != nullptr) memcpy(tags_out, g_trace_tags, sizeof(int) * 4 * (size_t)n);
+    g_trace_buf = nullptr; g_trace_cap = 0;
+    return n;
+}
+#endif

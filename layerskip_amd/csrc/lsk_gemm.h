@@ -21,6 +21,25 @@
 #pragma once
 #include "lsk_common.h"
 
+// The arguments a workgroup needs on its way to the first weight request and to the staged activation rows travel as EXPLICIT
+// kernel arguments in front of the parameter block: with -mllvm -amdgpu-kernarg-preload-count=14 (layerskip_amd/build.py) the
+// first 14 argument dwords are in SGPRs when the wave starts, instead of one scalar-memory round trip (~1 us on this chip next to
+// a weight stream, profiles/r03_kernel_timeline.md) later.  14 dwords: four pointers and six 32-bit words, two of each with a
+// meaning that depends on the kernel's (PRO, EPI) -- `lsk_gemm_hot_args` below packs them, `lsk_gemm_kernel` unpacks them.
+// Everything else stays in the block and is read at the top of the kernel, under the rows' and the ring's flight time.
+struct GemmHot {
+    const elem_t* x;        // = GemmParams::x, wp, ... (same meaning)
+    const elem_t* wp;
+    const elem_t* norm_w;   // PRO_RMS
+    elem_t* h;              // EPI_RESID
+    const int* kv_len;      // EPI_QKV
+    int ldx, M, K;
+    unsigned wp_bytes;
+    int n_tiles, tiles_per_wg, N;
+    float eps;              // PRO_RMS
+    int ldh;                // EPI_RESID
+};
+
 struct UnitInfo {
     unsigned off0;   // byte offset of this wave's first block of the unit (+ lane*16)
     int nvalid;      // valid k-steps of this wave in the unit (0..16)
@@ -71,7 +90,7 @@ __host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS
 // K-chunk into registers (issued before / under the weight stream), `lsk_store_chunk` applies the
 // RMSNorm (if any) and writes the bf16 rows to LDS later, without touching global memory.
 template <int PRO, int MB>
-__device__ __forceinline__ void lsk_load_chunk(const GemmParams& p, int c, int steps_c, int tid, elem8 (&xr)[MB], elem8& nw) {
+__device__ __forceinline__ void lsk_load_chunk(const GemmHot& p, int c, int steps_c, int tid, elem8 (&xr)[MB], elem8& nw) {
     if (PRO == PRO_PLAIN) {
         // EVERY thread loads, from a clamped (always valid) slice: no exec-masked region around the loads.  Inside such a region
         // hipcc ended the branch with register copies of the last row's value -- an s_waitcnt on 8 of the 12 outstanding loads in
@@ -106,7 +125,7 @@ __device__ __forceinline__ void lsk_accumulate_squares(const elem8 (&xr)[MB], bo
 }
 
 template <int PRO, int MB>
-__device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned char* xs, int xstride, const float (&sv)[MB],
+__device__ __forceinline__ void lsk_store_chunk(const GemmHot& p, unsigned char* xs, int xstride, const float (&sv)[MB],
                                                 int steps_c, int tid, const elem8 (&xr)[MB], const elem8& nw) {
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
@@ -129,7 +148,13 @@ __device__ __forceinline__ void lsk_store_chunk(const GemmParams& p, unsigned ch
 }
 
 template <int PRO, int EPI, int MB>
-__device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int block_id, unsigned char* smem) {
+__device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParams& p, const int block_id, unsigned char* smem) {
+    // q/k/v: the verified context length is read FIRST (its pointer is a preloaded argument): the answer is back when the ring has
+    // been requested.  (Nothing with side effects may stand before it, or hipcc makes it a vector load.)
+    int kv_now = 0;
+    if (EPI == EPI_QKV) kv_now = *hp.kv_len;
+    LSK_TRACE_DECL;
+    LSK_TRACE_POINT(0);                                           // first instruction of the workgroup
     float* slab = (float*)(smem + LSK_LDS_SLAB);
     float* red = (float*)(smem + LSK_LDS_RED);
     unsigned char* xs = smem + LSK_LDS_X;
@@ -137,77 +162,46 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ksteps = p.K >> 5;
+    const int M = hp.M;
+    const int ksteps = hp.K >> 5;
     const int nchunks = (ksteps + LSK_KC_STEPS - 1) / LSK_KC_STEPS;
-    const int tile0 = block_id * p.tiles_per_wg;
-    const int ntl = min(p.tiles_per_wg, p.n_tiles - tile0);
+    const int tile0 = block_id * hp.tiles_per_wg;
+    const int ntl = min(hp.tiles_per_wg, hp.n_tiles - tile0);
     const int units = nchunks * ntl;
-    const int xstride = lsk_gemm_xstride(p.K);
-    // Every kernel argument the prologue needs is read in ONE scalar-load clause: hipcc otherwise fetches the argument block
-    // lazily, a few fields at a time where they are first used -- three dependent kernarg round trips stood in front of the
-    // activation loads and the weight ring of every projection launch.  (No `volatile`: an asm with side effects in front of
-    // `*p.kv_len` below would make hipcc demote that scalar load to a vector load; the tie to M keeps the statement alive.)
-    int M = p.M;
-    asm("" : "+s"(M) : "s"(p.x), "s"(p.ldx), "s"(p.K), "s"(p.wp), "s"(p.wp_bytes), "s"(p.N), "s"(p.n_tiles), "s"(p.tiles_per_wg));
-    if (PRO == PRO_RMS) asm("" : "+s"(M) : "s"(p.norm_w), "s"(p.eps));
-    if (EPI == EPI_RESID) asm("" : "+s"(M) : "s"(p.h), "s"(p.ldh));
-    if (EPI == EPI_QKV) asm("" : "+s"(M) : "s"(p.kv_len), "s"(p.pos_off), "s"(p.rope_cos), "s"(p.rope_sin), "s"(p.block_table), "s"(p.page_size),
-                            "s"(p.n_heads), "s"(p.n_kv), "s"(p.head_dim));
-
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
-
-    // ---- epilogue operands first: everything the owner waves will need after the last MFMA that does not depend on
-    //      the product (residual values, RoPE cos/sin, KV page ids) is requested before the weight stream, so the
-    //      tail of the launch is arithmetic + stores instead of one or two dependent global-load round trips ----
+    const int xstride = lsk_gemm_xstride(hp.K);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hp.wp, 0, hp.wp_bytes, 0x00020000);
     const int c16 = lane & 15;
     const int rg = lane >> 4;
     const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : ntl;
     const bool is_owner = w < n_owned;
-    // The values are kept RAW (model dtype) and every lane loads from a clamped, always-valid address: a conversion or a
-    // lane predicate at the load makes hipcc wait for each load where it stands (branch around it + s_waitcnt vmcnt(0)), which
-    // put 1-4 SERIAL L2 round trips in front of the owner waves' activation loads and weight ring -- the whole workgroup
-    // then waited for them at the first barrier (ISA of the round-2 build: 4 waited global_load_ushort at the top of the
-    // o_proj / down kernels of a verify pass, 4 waited cos/sin pairs + 4 block-table loads at the top of q/k/v).
-    elem_t pre_a[4], pre_b[4];                  // RESID: residual values (pre_a) | QKV: cos, sin
-    int pre_pg[4] = {0, 0, 0, 0};               // QKV: KV page of each row's position
+
+    // ---- epilogue operands: everything the owner waves will need after the last MFMA that does not depend on the product
+    //      (residual values, RoPE cos/sin, KV page ids) is requested EARLY, so that the tail of the launch is arithmetic + stores
+    //      instead of one or two dependent global-load round trips.  WHERE matters (profiles/r03_kernel_timeline.md): a vector
+    //      memory instruction issued behind the eight waves' ring fills waits ~1 us in the CU's address queue (128 KiB at 64 B per
+    //      clock) and holds its wave with it, and a dependent scalar read in front of the ring delays the ring by a round trip.
+    //      So: the residual values (addresses from preloaded arguments only) go out FIRST, in front of the rows and the ring; the
+    //      q/k/v operands (addresses from the device-side context length and the block's fields, read at the top of the kernel)
+    //      go out once the rows are staged -- the queue has drained by then, the scalars are back, and the values still land long
+    //      before the epilogue (a wave's loads retire in order: behind the first unit's fragments) ----
+    // (Deliberately NOT initialised: a default value is a second write to the registers a load on the other path targets, and at
+    // the merge hipcc then waits for EVERY outstanding load -- the whole weight ring -- in the waves that took the path without
+    // loads (ISA: s_waitcnt vmcnt(0) in front of the v tiles' waves).  Each array is read only where it was loaded.)
+    elem_t pre_a[4], pre_b[4];                  // RESID: residual values (pre_a) | QKV: cos, sin (q and k tiles)
+    int pre_pg[4];                              // QKV: KV page of each row's position (k and v tiles)
     int base_pos = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { pre_a[i] = (elem_t)0.0f; pre_b[i] = (elem_t)0.0f; }
+    // EVERY wave loads, owner of a tile or not, whatever the tile holds, from clamped (always valid) addresses: straight-line code.
+    // Behind a wave-uniform branch hipcc merged the paths with an s_waitcnt vmcnt(0) (a scratch register of the untaken side aliased
+    // the last load's target), i.e. the k and v tiles' waves waited for their whole weight ring before staging their rows.
     if (EPI == EPI_RESID) {
-        if (is_owner) {
-            const int n = min((tile0 + w) * 16 + c16, p.N - 1);
+        const int n = min((tile0 + w) * 16 + c16, hp.N - 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pre_a[i] = p.h[(size_t)min(rg * 4 + i, M - 1) * p.ldh + n];
-        }
-    } else if (EPI == EPI_QKV) {
-        base_pos = *p.kv_len + p.pos_off;
-        if (is_owner) {
-            const int hd = p.head_dim;
-            const int tph = hd >> 4;
-            const int T = tile0 + w;
-            const int nq_t = p.n_heads * tph;
-            const int nk_t = p.n_kv * tph;
-            const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);
-            const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
-            const int tt = TT - (TT / tph) * tph;
-            const int j = tt * 8 + (c16 & 7);
-            if (kind != 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pos = base_pos + min(rg * 4 + i, M - 1);
-                    pre_a[i] = p.rope_cos[(size_t)pos * (hd >> 1) + j];
-                    pre_b[i] = p.rope_sin[(size_t)pos * (hd >> 1) + j];
-                }
-            }
-            if (kind != 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pre_pg[i] = p.block_table[(base_pos + min(rg * 4 + i, M - 1)) / p.page_size];
-            }
-        }
+        for (int i = 0; i < 4; ++i) pre_a[i] = hp.h[(size_t)min(rg * 4 + i, M - 1) * hp.ldh + n];
     }
 
     // ---- activations next (they must not queue behind the weight ring), then fill the ring ----
     UnitInfo cur = lsk_unit_info(0, units, ntl, ksteps, tile0, w, lane);
+    LSK_TRACE_POINT(9);                                           // address arithmetic done, nothing requested yet
     elem8 xr[MB];
     elem8 nw = {};
     float ss[MB];
@@ -219,23 +213,25 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
         // RMSNorm statistics need whole rows: walk the K-chunks last-to-first so chunk 0 stays in xr
         for (int c = nchunks - 1; c >= 1; --c) {
             const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
-            lsk_load_chunk<PRO, MB>(p, c, steps_c, tid, xr, nw);
+            lsk_load_chunk<PRO, MB>(hp, c, steps_c, tid, xr, nw);
             lsk_accumulate_squares<MB>(xr, tid * 8 < steps_c * 32, ss);
         }
         // chunk 0 is only REQUESTED here: the weight ring is queued right behind it, so the first HBM round trip of the
         // stream overlaps the round trip of the rows instead of following it (a wave's loads retire in order: the rows
         // arrive first, the statistics below run under the ring's flight time)
-        lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
+        lsk_load_chunk<PRO, MB>(hp, 0, cur.steps_c, tid, xr, nw);
     } else {
-        lsk_load_chunk<PRO, MB>(p, 0, cur.steps_c, tid, xr, nw);
+        lsk_load_chunk<PRO, MB>(hp, 0, cur.steps_c, tid, xr, nw);
     }
 #pragma unroll
     for (int s = 0; s < LSK_SPW; ++s) {
         const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
         ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
     }
+    LSK_TRACE_POINT(1);                                           // rows and weight ring requested
     if (PRO == PRO_RMS) {
         lsk_accumulate_squares<MB>(xr, tid * 8 < cur.steps_c * 32, ss);
+        LSK_TRACE_POINT(8);                                       // wave 0's slice of the rows arrived (first use)
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const float t = wave_sum(ss[i]);
@@ -249,15 +245,40 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             float t = 0.f;
 #pragma unroll
             for (int ww = 0; ww < LSK_WAVES; ++ww) t += red[lane * LSK_WAVES + ww];
-            my_inv = 1.0f / sqrtf(t / (float)p.K + p.eps);
+            my_inv = 1.0f / sqrtf(t / (float)hp.K + hp.eps);
         }
 #pragma unroll
         for (int i = 0; i < MB; ++i)
             sv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_inv), i));
     }
-    lsk_store_chunk<PRO, MB>(p, xs, xstride, sv, cur.steps_c, tid, xr, nw);
-    if (nchunks > 1) lsk_load_chunk<PRO, MB>(p, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);   // prefetch chunk 1
+    lsk_store_chunk<PRO, MB>(hp, xs, xstride, sv, cur.steps_c, tid, xr, nw);
+#ifdef LSK_TRACE
+    if (PRO == PRO_PLAIN) LSK_TRACE_POINT(8);                     // wave 0's slice of the rows arrived and went to LDS
+#endif
     __syncthreads();
+    LSK_TRACE_POINT(2);                                           // rows arrived, normalised, staged
+    // prefetch of chunk 1's rows: BEHIND the barrier -- in front of it the requests waited in the CU's address queue behind the eight
+    // waves' ring fills and held the whole workgroup at the barrier with them (down_proj of a verify pass: rows staged 1.4 us earlier)
+    if (nchunks > 1) lsk_load_chunk<PRO, MB>(hp, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);
+    // (q/k/v: the block's fields the operand addresses need are read in ONE scalar clause -- hipcc issues it at the top of the kernel,
+    // the pin only keeps it from sinking the reads to their uses, one dependent round trip each)
+    if (EPI == EPI_QKV) asm volatile("" : : "s"(kv_now), "s"(p.pos_off), "s"(p.rope_cos), "s"(p.rope_sin), "s"(p.block_table), "s"(p.page_size),
+                                     "s"(p.n_heads), "s"(p.n_kv), "s"(p.head_dim));
+    if (EPI == EPI_QKV) {
+        base_pos = kv_now + p.pos_off;
+        const int hd = p.head_dim;
+        const int tph = hd >> 4;
+        const int TT = tile0 + w;                               // cos / sin column: the same function of the tile index for q and k
+        const int tt = TT - (TT / tph) * tph;                   // tiles (whole heads of hd / 16 tiles each precede both ranges)
+        const int j = tt * 8 + (c16 & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pos = base_pos + min(rg * 4 + i, M - 1);
+            pre_a[i] = p.rope_cos[(size_t)pos * (hd >> 1) + j];
+            pre_b[i] = p.rope_sin[(size_t)pos * (hd >> 1) + j];
+            pre_pg[i] = p.block_table[pos / p.page_size];
+        }
+    }
 
     const int arow = min(lane & 15, M - 1);
     const unsigned char* xa = xs + (size_t)arow * xstride + (lane >> 4) * 16;
@@ -277,9 +298,9 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
         if (nchunks > 1 && cur.tl == 0 && u > 0) {
             // every wave passed the previous unit's barrier => nobody still reads the old chunk; the rows
             // of this chunk were prefetched into xr one chunk ago, the next chunk's are requested now
-            lsk_store_chunk<PRO, MB>(p, xs, xstride, sv, cur.steps_c, tid, xr, nw);
+            lsk_store_chunk<PRO, MB>(hp, xs, xstride, sv, cur.steps_c, tid, xr, nw);
             if (cur.c + 1 < nchunks)
-                lsk_load_chunk<PRO, MB>(p, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
+                lsk_load_chunk<PRO, MB>(hp, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const elem8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
@@ -288,6 +309,10 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
         for (int s = 0; s < LSK_SPW; ++s) {
             acc = LSK_MFMA_16x16x32(afr[s], __builtin_bit_cast(elem8, ring[s]), acc, 0, 0, 0);
+#ifdef LSK_TRACE
+            if (u == 0 && s == 0) LSK_TRACE_POINT(3);             // first weight fragment arrived
+            if (u == 0 && s == LSK_SPW - 1) LSK_TRACE_POINT(4);   // first unit's fragments all arrived
+#endif
             const unsigned off = (s < nxt.nvalid) ? nxt.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
             ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
             // (hipcc sinks these refills into bursts behind later MFMAs, so the ring runs ~8-16 deep; pinning
@@ -307,6 +332,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
         }
         cur = nxt;
     }
+    LSK_TRACE_POINT(5);                                           // last unit reduced
 
     // ---- epilogue: owner wave `ow` holds tile (tile0 + ow) [pair ow for SWIGLU] in C layout ----
 
@@ -316,7 +342,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
-                if (row < M && n < p.N) p.y[(size_t)row * p.N + n] = own0[i];
+                if (row < M && n < hp.N) p.y[(size_t)row * hp.N + n] = own0[i];
             }
         }
     } else if (EPI == EPI_RESID) {
@@ -325,8 +351,8 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
-                if (row < M && n < p.N) {
-                    p.h[(size_t)row * p.ldh + n] = f2e(e2f(pre_a[i]) + rnd_e(own0[i]));   // residual + Linear(...) in model dtype
+                if (row < M && n < hp.N) {
+                    hp.h[(size_t)row * hp.ldh + n] = f2e(e2f(pre_a[i]) + rnd_e(own0[i]));   // residual + Linear(...) in model dtype
                 }
             }
         }
@@ -336,7 +362,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
-                if (row < M && n < (p.N >> 1)) {
+                if (row < M && n < (hp.N >> 1)) {
                     const float g = rnd_e(own0[i]);                    // gate_proj(x)
                     const float uu = rnd_e(own1[i]);                   // up_proj(x)
                     const float s = rnd_e(g / (1.0f + expf(-g)));      // silu in fp32, one rounding
@@ -395,9 +421,9 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             for (int i = 0; i < 4; ++i) {
                 const int row = rg * 4 + i;
                 float v = rnd_e(own0[i]);                              // logits in model dtype
-                if (p.logits != nullptr && row < M && n < p.N) p.logits[(size_t)row * p.ld_logits + n] = v;
+                if (p.logits != nullptr && row < M && n < hp.N) p.logits[(size_t)row * p.ld_logits + n] = v;
                 int idx = n;
-                if (n >= p.N) { v = -INFINITY; idx = 0x7fffffff; }
+                if (n >= hp.N) { v = -INFINITY; idx = 0x7fffffff; }
                 // argmax over the tile's 16 columns, first (lowest) index wins ties like torch.argmax
                 // row rotations (DPP, a few cycles each) instead of ds_bpermute round trips: the (value, index) maximum with
                 // the lowest-index tie-break is associative and commutative, so after rotations by 8, 4, 2, 1 every lane of
@@ -424,10 +450,37 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmParams& p, const int blo
             p.part_idx[block_id * 16 + tid] = idx;
         }
     }
+#ifdef LSK_TRACE
+    LSK_TRACE_POINT(6);                                           // epilogue stores issued (wave 0's view)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LSK_TRACE_POINT(7);                                           // ... and acknowledged
+    LSK_TRACE_FLUSH(p, block_id);
+#endif
 }
 
 template <int PRO, int EPI, int MB>
-__global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const elem_t* x, const elem_t* wp, const void* a2, const void* a3, int ldx, int K,
+                                                               unsigned wp_bytes, int N, int m_tpw, unsigned e0, const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    lsk_gemm_body<PRO, EPI, MB>(p, blockIdx.x, smem);
+    GemmHot hp;
+    hp.x = x; hp.wp = wp; hp.ldx = ldx; hp.K = K; hp.wp_bytes = wp_bytes; hp.N = N;
+    hp.M = m_tpw & 0xff; hp.tiles_per_wg = m_tpw >> 8; hp.n_tiles = (N + 15) >> 4;
+    hp.norm_w = (PRO == PRO_RMS) ? (const elem_t*)a2 : nullptr;
+    hp.eps = (PRO == PRO_RMS) ? __builtin_bit_cast(float, e0) : 0.f;
+    hp.h = (EPI == EPI_RESID) ? (elem_t*)const_cast<void*>(a2) : nullptr;
+    hp.ldh = (EPI == EPI_RESID) ? (int)e0 : 0;
+    hp.kv_len = (EPI == EPI_QKV) ? (const int*)a3 : nullptr;
+    lsk_gemm_body<PRO, EPI, MB>(hp, p, blockIdx.x, smem);
 }
+
+// the explicit-argument list of a launch, from the block (host side)
+template <int PRO, int EPI>
+struct GemmHotArgs {
+    const void* a2; const void* a3; int m_tpw; unsigned e0;
+    explicit GemmHotArgs(const GemmParams& p) {
+        a2 = (PRO == PRO_RMS) ? (const void*)p.norm_w : (EPI == EPI_RESID ? (const void*)p.h : nullptr);   // (no kernel is both)
+        a3 = (EPI == EPI_QKV) ? (const void*)p.kv_len : nullptr;
+        m_tpw = p.M | (p.tiles_per_wg << 8);
+        e0 = (PRO == PRO_RMS) ? __builtin_bit_cast(unsigned, p.eps) : (EPI == EPI_RESID ? (unsigned)p.ldh : 0u);
+    }
+};

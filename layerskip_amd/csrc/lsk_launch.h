@@ -37,6 +37,23 @@ static int init_kernel_attrs() {
     return 0;
 }
 
+#ifdef LSK_TRACE
+// measurement builds (tools/kernel_timeline.py): the host side of the in-kernel timeline -- every traced launch gets the next
+// slot of the caller's buffer and a tag (kernel kind, rows, grid)
+static unsigned long long* g_trace_buf = nullptr;
+static int g_trace_cap = 0, g_trace_seq = 0, g_trace_skip = 0;
+static int g_trace_tags[8192][4];
+static LskTrace lsk_trace_next(int kind, int sub, int m, int grid) {
+    LskTrace t{nullptr, 0};
+    if (g_trace_buf != nullptr && g_trace_skip > 0) { --g_trace_skip; return t; }
+    if (g_trace_buf != nullptr && g_trace_seq < g_trace_cap && g_trace_seq < 8192) {
+        g_trace_tags[g_trace_seq][0] = kind; g_trace_tags[g_trace_seq][1] = sub; g_trace_tags[g_trace_seq][2] = m; g_trace_tags[g_trace_seq][3] = grid;
+        t.buf = g_trace_buf; t.seq = g_trace_seq++;
+    }
+    return t;
+}
+#endif
+
 static int tiles_per_wg(int n_units, int target_wgs) {   // units = tiles (or gate/up pairs)
     int t = (n_units + target_wgs - 1) / target_wgs;
     return t < 1 ? 1 : (t > 8 ? 8 : t);
@@ -44,8 +61,12 @@ static int tiles_per_wg(int n_units, int target_wgs) {   // units = tiles (or ga
 
 template <int PRO, int EPI, int MB>
 static void launch_gemm_mb(const GemmParams& p, int grid, size_t lds, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    if (ev_start != nullptr) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0, p);
-    else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB>), dim3(grid), dim3(LSK_THREADS), lds, st, p);
+    // the fields a workgroup needs before its first weight request ride in front of the block (GemmHot, lsk_gemm.h)
+    const GemmHotArgs<PRO, EPI> a(p);
+    if (ev_start != nullptr) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0,
+                                                   p.x, p.wp, a.a2, a.a3, p.ldx, p.K, p.wp_bytes, p.N, a.m_tpw, a.e0, p);
+    else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB>), dim3(grid), dim3(LSK_THREADS), lds, st,
+                            p.x, p.wp, a.a2, a.a3, p.ldx, p.K, p.wp_bytes, p.N, a.m_tpw, a.e0, p);
 }
 
 template <int PRO, int EPI>
@@ -56,9 +77,13 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
     p.tiles_per_wg = tiles_per_wg(n_units, target_wgs) * unit;
     const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
+    if (p.n_tiles != (p.N + 15) / 16) return lsk_fail("gemm: n_tiles %d is not ceil(N / 16) of N = %d", p.n_tiles, p.N);   // the kernel derives it
     if (lds > kMaxGemmLds) return lsk_fail("gemm LDS %zu exceeds %zu", lds, kMaxGemmLds);
     // 32-bit buffer offsets; the out-of-range sentinel of ragged ring slots must stay beyond the descriptor's range
     if ((size_t)p.n_tiles * 16 * (size_t)p.K * 2 >= (size_t)LSK_OOB_OFFSET) return lsk_fail("packed weight of %d x %d exceeds the 32-bit buffer range", p.n_tiles * 16, p.K);
+#ifdef LSK_TRACE
+    p.trace = lsk_trace_next(0, (PRO * 16 + EPI) | (p.K << 8), p.M, grid);
+#endif
     // profiling (ev_start != nullptr): the events are bound to THIS dispatch's own begin / end timestamps (what rocprofv3 reports)
     if (p.M == 1) launch_gemm_mb<PRO, EPI, 1>(p, grid, lds, st, ev_start, ev_stop);
     else if (p.M <= LSK_MB_MID) launch_gemm_mb<PRO, EPI, LSK_MB_MID>(p, grid, lds, st, ev_start, ev_stop);

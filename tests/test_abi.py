@@ -111,27 +111,39 @@ def test_error_messages_come_from_the_library_that_failed():
         _lib.check(1, b)
 
 
-def test_no_kernel_spills_to_scratch():
-    """Every kernel of the product library stays in registers (hipcc -Rpass-analysis=kernel-resource-usage: ScratchSize 0).  A spill
-    changes no result, only the speed: the 16-row templates of the skinny projection kernel sit at the 256-register limit and an
-    innocent-looking edit of the prologue pushed them into scratch (llama2-13B verify passes 30 % slower) -- no parity test sees that."""
+def test_kernel_resources_of_the_product_build():
+    """Two properties of the compiled kernels no parity test sees (read from the kernel descriptors in the device assembly of the product
+    sources, built with the product flags):
+    * every kernel stays in registers (ScratchSize 0).  A spill changes no result, only the speed: the 16-row templates of the
+      skinny projection kernel sit at the 256-register limit and an innocent-looking edit of the prologue pushed them into scratch
+      (llama2-13B verify passes 30 % slower);
+    * the decode kernels get their first 14 argument dwords preloaded into SGPRs (kernel descriptor field
+      kernarg_preload_length): without it every launch starts with a ~1 us scalar round trip (profiles/r03_kernel_timeline.md)."""
     import re
     import subprocess
     import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     from layerskip_amd import build
     csrc = os.path.join(ROOT, "layerskip_amd", "csrc")
-    with tempfile.TemporaryDirectory() as td:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(td, "x.so")] + [os.path.join(csrc, s) for s in build.SOURCES]
-        proc = subprocess.run(cmd, capture_output=True, text=True)
-    assert proc.returncode == 0, proc.stderr[-2000:]
-    blocks = re.split(r"remark: [^\n]*Function Name: ", proc.stderr)[1:]
-    assert len(blocks) >= 40
-    spilled = []
-    for b in blocks:
-        name = b.split("\n")[0].strip().split()[0]
-        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b)
-        assert m, name
-        if int(m.group(1)) != 0:
-            spilled.append((name, int(m.group(1))))
+
+    def device_asm(src):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "x.s")
+            proc = subprocess.run(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["--cuda-device-only", "-S", "-o", out, os.path.join(csrc, src)],
+                                  capture_output=True, text=True)
+            assert proc.returncode == 0, proc.stderr[-2000:]
+            return open(out).read()
+
+    with ThreadPoolExecutor(max_workers=len(build.SOURCES)) as pool:
+        texts = list(pool.map(device_asm, build.SOURCES))
+    kernels = {}
+    for text in texts:
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S):
+            scratch = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
+            pre = re.search(r"\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", m.group(2))
+            kernels[m.group(1)] = {"scratch": int(scratch.group(1)), "preload": int(pre.group(1)) if pre else 0}
+    assert len(kernels) >= 40
+    spilled = {k: v["scratch"] for k, v in kernels.items() if v["scratch"] != 0}
     assert not spilled, spilled
+    decode = {k: v["preload"] for k, v in kernels.items() if "lsk_gemm_kernel" in k or "lsk_attn_split_kernel" in k}
+    assert len(decode) >= 20 and all(n == 14 for n in decode.values()), decode

@@ -8,6 +8,9 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from layerskip_amd.build import HIPCC_FLAGS  # noqa: E402
+
 CSRC = os.path.join(ROOT, "layerskip_amd", "csrc")
 
 
@@ -16,8 +19,8 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         rows = []
         for src in srcs:
-            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                   "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(td, "x.so"), src] + sys.argv[1:]
+            cmd = ["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(td, "x.so"),
+                                              src] + sys.argv[1:]
             txt = subprocess.run(cmd, capture_output=True, text=True).stderr
             for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
                 name = b.split("\n")[0].strip().split()[0]
