@@ -147,6 +147,28 @@ __device__ __forceinline__ void lsk_store_chunk(const GemmHot& p, unsigned char*
     }
 }
 
+// lm_head: one finished tile (column n of this lane, rows rg * 4 + i) folded into the wave's running (value, index) maximum per row --
+// logits rounded to the model dtype first, lowest index wins ties like torch.argmax (over the tile's 16 columns by DPP row
+// rotations: the maximum with that tie-break is associative and commutative, so after rotations by 8, 4, 2, 1 every lane of the
+// 16-lane row holds the row's result; rows >= M of a short pass are skipped)
+__device__ __forceinline__ void lsk_head_tile(const GemmParams& p, const f32x4& sums, int n, int N, int M, int rg, float (&rbv)[4], int (&rbi)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = rg * 4 + i;
+        float v = rnd_e(sums[i]);                                    // logits in model dtype
+        if (p.logits != nullptr && row < M && n < N) p.logits[(size_t)row * p.ld_logits + n] = v;
+        int idx = n;
+        if (n >= N) { v = -INFINITY; idx = 0x7fffffff; }
+        if (i < M) {
+            lsk_row16_argmax_step<8>(v, idx);
+            lsk_row16_argmax_step<4>(v, idx);
+            lsk_row16_argmax_step<2>(v, idx);
+            lsk_row16_argmax_step<1>(v, idx);
+        }
+        if (v > rbv[i] || (v == rbv[i] && idx < rbi[i])) { rbv[i] = v; rbi[i] = idx; }
+    }
+}
+
 template <int PRO, int EPI, int MB>
 __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParams& p, const int block_id, unsigned char* smem) {
     // q/k/v: the verified context length is read FIRST (its pointer is a preloaded argument): the answer is back when the ring has
@@ -172,7 +194,10 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hp.wp, 0, hp.wp_bytes, 0x00020000);
     const int c16 = lane & 15;
     const int rg = lane >> 4;
-    const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : ntl;
+    // lm_head launches whose K fits one chunk may own MORE than 8 tiles (a 128 256-entry vocabulary is 8 016 tiles: 1 002 workgroups of
+    // 8 ran as four rounds on the 256 CUs, each with its own ramp and tail): tile tl then belongs to wave tl % 8 and is finished --
+    // rounded, compared -- the moment its only unit has been reduced (lsk_head_tile below)
+    const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : (ntl < LSK_WAVES ? ntl : LSK_WAVES);
     const bool is_owner = w < n_owned;
 
     // ---- epilogue operands: everything the owner waves will need after the last MFMA that does not depend on the product
@@ -285,6 +310,8 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
 
     f32x4 own0 = {0.f, 0.f, 0.f, 0.f};
     f32x4 own1 = {0.f, 0.f, 0.f, 0.f};
+    float rbv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // EPI_HEAD: this wave's running maximum per row ...
+    int rbi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // ... and its column
 
     // A wave owns the same k-steps of every tile of a K-chunk, so its 16 A fragments are read from LDS once per
     // chunk and stay in VGPRs: the unit loop then waits on the weight stream only (with a ds_read in front of
@@ -322,13 +349,15 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
         float* sl = slab + ((u & 1) * LSK_WAVES + w) * 256;
         *(f32x4*)(sl + lane * 4) = acc;
         __syncthreads();
-        const int owner = (EPI == EPI_SWIGLU) ? (cur.tl >> 1) : cur.tl;
+        const int owner = (EPI == EPI_SWIGLU) ? (cur.tl >> 1) : (EPI == EPI_HEAD ? (cur.tl & (LSK_WAVES - 1)) : cur.tl);
         if (w == owner) {
             const float* sb = slab + (u & 1) * LSK_WAVES * 256 + lane * 4;
             f32x4 t = *(const f32x4*)sb;
 #pragma unroll
             for (int ww = 1; ww < LSK_WAVES; ++ww) t += *(const f32x4*)(sb + ww * 256);
-            if (EPI == EPI_SWIGLU && (cur.tl & 1)) own1 += t; else own0 += t;
+            if (EPI == EPI_HEAD && nchunks == 1) lsk_head_tile(p, t, (tile0 + cur.tl) * 16 + c16, hp.N, M, rg, rbv, rbi);
+            else if (EPI == EPI_SWIGLU && (cur.tl & 1)) own1 += t;
+            else own0 += t;
         }
         cur = nxt;
     }
@@ -416,25 +445,10 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
         float* best_v = (float*)(smem + LSK_LDS_BESTV);
         int* best_i = (int*)(smem + LSK_LDS_BESTI);
         if (is_owner) {
-            const int n = (tile0 + w) * 16 + c16;
+            if (nchunks > 1) lsk_head_tile(p, own0, (tile0 + w) * 16 + c16, hp.N, M, rg, rbv, rbi);   // (<= 8 tiles: tile w, summed over the chunks)
+            if (c16 == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = rg * 4 + i;
-                float v = rnd_e(own0[i]);                              // logits in model dtype
-                if (p.logits != nullptr && row < M && n < hp.N) p.logits[(size_t)row * p.ld_logits + n] = v;
-                int idx = n;
-                if (n >= hp.N) { v = -INFINITY; idx = 0x7fffffff; }
-                // argmax over the tile's 16 columns, first (lowest) index wins ties like torch.argmax
-                // row rotations (DPP, a few cycles each) instead of ds_bpermute round trips: the (value, index) maximum with
-                // the lowest-index tie-break is associative and commutative, so after rotations by 8, 4, 2, 1 every lane of
-                // the 16-lane row holds the row's result; rows >= M of a short pass are skipped (i >= M: no lane group has one)
-                if (i < M) {
-                    lsk_row16_argmax_step<8>(v, idx);
-                    lsk_row16_argmax_step<4>(v, idx);
-                    lsk_row16_argmax_step<2>(v, idx);
-                    lsk_row16_argmax_step<1>(v, idx);
-                }
-                if (c16 == 0) { best_v[w * 16 + row] = v; best_i[w * 16 + row] = idx; }
+                for (int i = 0; i < 4; ++i) { best_v[w * 16 + rg * 4 + i] = rbv[i]; best_i[w * 16 + rg * 4 + i] = rbi[i]; }
             }
         }
         __syncthreads();

@@ -54,9 +54,9 @@ static LskTrace lsk_trace_next(int kind, int sub, int m, int grid) {
 }
 #endif
 
-static int tiles_per_wg(int n_units, int target_wgs) {   // units = tiles (or gate/up pairs)
+static int tiles_per_wg(int n_units, int target_wgs, int max_units = 8) {   // units = tiles (or gate/up pairs)
     int t = (n_units + target_wgs - 1) / target_wgs;
-    return t < 1 ? 1 : (t > 8 ? 8 : t);
+    return t < 1 ? 1 : (t > max_units ? max_units : t);
 }
 
 template <int PRO, int EPI, int MB>
@@ -74,7 +74,10 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
                        hipEvent_t ev_stop = nullptr) {
     const int unit = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int n_units = p.n_tiles / unit;
-    p.tiles_per_wg = tiles_per_wg(n_units, target_wgs) * unit;
+    // a wave keeps one accumulator per owned tile across the K-chunks: <= 8 tiles (gate/up pairs) per workgroup -- except for the
+    // lm_head when K is a single chunk, where a tile is finished as soon as its unit is (lsk_head_tile): any number
+    const int max_units = (EPI == EPI_HEAD && p.K <= LSK_KC_ELEMS) ? (1 << 20) : 8;
+    p.tiles_per_wg = tiles_per_wg(n_units, target_wgs, max_units) * unit;
     const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
     if (p.n_tiles != (p.N + 15) / 16) return lsk_fail("gemm: n_tiles %d is not ceil(N / 16) of N = %d", p.n_tiles, p.N);   // the kernel derives it

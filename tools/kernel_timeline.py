@@ -93,6 +93,11 @@ def main():
             for k, pn in enumerate(GEMM_POINTS):
                 rec[pn] = float(np.median(rel[:, k]))
                 rec[pn + "_max"] = float(rel[:, k].max())
+            xcd = d[:, 11] & 0xF
+            for x in range(8):                                    # when the workgroups of each XCD finish (mean; NaN: none there)
+                rec[f"reduced_xcd{x}"] = float(np.mean(rel[xcd == x, 4])) if (xcd == x).any() else float("nan")
+            rec["reduced_p10"] = float(np.percentile(rel[:, 4], 10))
+            rec["reduced_p90"] = float(np.percentile(rel[:, 4], 90))
             rec["own_ring_req"] = float(np.median((d[:, 1] - t0) * TICK_US))      # first instruction -> ring requested, per workgroup
             rec["own_addr_done"] = float(np.median((d[:, 9] - t0) * TICK_US))
             rec["rows_wave0"] = float(np.median((d[:, 8] - start) * TICK_US))
