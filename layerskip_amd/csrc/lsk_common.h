@@ -68,6 +68,15 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+// One step of the (value, index) maximum over a 16-lane row, lowest index wins ties (torch.argmax): the lane takes the pair of
+// the lane ROT places to its right if that is better.
+template <int ROT>
+__device__ __forceinline__ void lsk_row16_argmax_step(float& v, int& idx) {
+    const float ov = lsk_dpp<LSK_ROW_ROR(ROT)>(v);
+    const int oi = lsk_dpp<LSK_ROW_ROR(ROT)>(idx);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
+
 // Sum over the 64 lanes of a wave, same value (wave-uniform) in every lane: four row sums, then the four row
 // totals through v_readlane in a fixed order.
 __device__ __forceinline__ float wave_sum(float v) {

@@ -65,13 +65,6 @@ __device__ __forceinline__ UnitInfo lsk_unit_info(int u, int units, int ntl, int
 
 #define LSK_OOB_OFFSET 0xF0000000u
 
-template <int ROT>
-__device__ __forceinline__ void lsk_row16_argmax_step(float& v, int& idx) {
-    const float ov = lsk_dpp<LSK_ROW_ROR(ROT)>(v);
-    const int oi = lsk_dpp<LSK_ROW_ROR(ROT)>(idx);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-}
-
 // LDS carve (bytes)
 #define LSK_LDS_SLAB 0          // [2][8][256] f32 = 16384
 #define LSK_LDS_RED 16384       // [16][8] f32 = 512

@@ -59,13 +59,22 @@ __global__ void lsk_argmax_finalize_kernel(const float* __restrict__ part_val, c
             const int oi = part_idx[i * 16 + row];
             if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
         }
+        // 64 lanes -> 1: DPP rotations inside the four 16-lane rows, then the four row results through v_readlane (the maximum with the
+        // lowest-index tie-break is associative and commutative; six __shfl_xor steps were twelve LDS-pipe round trips of this
+        // latency-bound kernel)
+        lsk_row16_argmax_step<8>(v, idx);
+        lsk_row16_argmax_step<4>(v, idx);
+        lsk_row16_argmax_step<2>(v, idx);
+        lsk_row16_argmax_step<1>(v, idx);
+        float bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+        int bi = __builtin_amdgcn_readlane(idx, 0);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(v, o, 64);
-            const int oi = __shfl_xor(idx, o, 64);
-            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        for (int r = 1; r < 4; ++r) {
+            const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r * 16));
+            const int oi = __builtin_amdgcn_readlane(idx, r * 16);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if (threadIdx.x == 0) { tokens_out[row] = idx; s_tok = idx; }
+        if (threadIdx.x == 0) { tokens_out[row] = bi; s_tok = bi; }
     }
     if (embed_dst == nullptr) return;
     __syncthreads();
