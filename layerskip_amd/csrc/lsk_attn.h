@@ -207,27 +207,71 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
     __syncthreads();
     LSK_TRACE_POINT(3);                                           // O = P V of the 4 waves in LDS
     // ---- merge the 4 waves (fixed order) into the page partial of each (head, row) ----
-    for (int e = tid; e < n_rows * PSTRIDE; e += LSK_ATTN_THREADS) {
-        const int i = e / PSTRIDE;
-        const int d = e - i * PSTRIDE;
-        float m = LSK_ATTN_NEG;
+    // Two forms, the same sums: one element per work item while that is a single trip of the loop (a one-row pass: 130 items --
+    // the shortest dependent chain per thread, which is what this latency-bound kernel pays for), four adjacent features per item
+    // beyond that (a 7-row verify pass: 231 items, ONE trip instead of four; the rescale factors of the 4 waves once per item, LDS
+    // reads and write-through stores 8 bytes wide).  Every element keeps its own sum, in wave order, in both.
+    if (n_rows * PSTRIDE <= LSK_ATTN_THREADS) {
+        for (int e = tid; e < n_rows * PSTRIDE; e += LSK_ATTN_THREADS) {
+            const int i = e / PSTRIDE;
+            const int d = e - i * PSTRIDE;
+            float m = LSK_ATTN_NEG;
 #pragma unroll
-        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + i) * PSTRIDE + HD]);
-        float v;
-        if (d == HD) {
-            v = m;
-        } else {
-            v = 0.f;
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + i) * PSTRIDE + HD]);
+            float v;
+            if (d == HD) {
+                v = m;
+            } else {
+                v = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
-                const float* src = sm + (ww * 16 + i) * PSTRIDE;
-                v += src[d] * __builtin_amdgcn_exp2f(src[HD] - m);      // d == HD + 1: the running sum l
+                for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
+                    const float* src = sm + (ww * 16 + i) * PSTRIDE;
+                    v += src[d] * __builtin_amdgcn_exp2f(src[HD] - m);      // d == HD + 1: the running sum l
+                }
+            }
+            const int ih = (i * inv_m) >> 8;
+            float* dstp = p.part + (((size_t)(head0 + ih) * p.max_pages + page_l) * LSK_ROWS + (i - ih * M)) * PSTRIDE + d;
+            if (fused) __hip_atomic_store(dstp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+            else *dstp = v;
+        }
+    } else {
+        constexpr int QPR = HD / 4 + 1;                              // items per row: HD / 4 feature quads + the (max, sum) pair
+        for (int e = tid; e < n_rows * QPR; e += LSK_ATTN_THREADS) {
+            const int i = e / QPR;
+            const int q = e - i * QPR;
+            float f[LSK_ATTN_WAVES];
+            float m = LSK_ATTN_NEG;
+#pragma unroll
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) { f[ww] = sm[(ww * 16 + i) * PSTRIDE + HD]; m = fmaxf(m, f[ww]); }
+#pragma unroll
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) f[ww] = __builtin_amdgcn_exp2f(f[ww] - m);
+            const int ih = (i * inv_m) >> 8;
+            float* rowp = p.part + (((size_t)(head0 + ih) * p.max_pages + page_l) * LSK_ROWS + (i - ih * M)) * PSTRIDE;
+            const int d = (q < HD / 4) ? q * 4 : HD;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q < HD / 4) {
+#pragma unroll
+                for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
+                    const float2 a = *(const float2*)(sm + (ww * 16 + i) * PSTRIDE + d);        // 8-byte aligned: PSTRIDE and d are even
+                    const float2 b = *(const float2*)(sm + (ww * 16 + i) * PSTRIDE + d + 2);
+                    v[0] += a.x * f[ww]; v[1] += a.y * f[ww]; v[2] += b.x * f[ww]; v[3] += b.y * f[ww];
+                }
+            } else {
+                v[0] = m;
+#pragma unroll
+                for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) v[1] += sm[(ww * 16 + i) * PSTRIDE + HD + 1] * f[ww];   // the running sum l
+            }
+            const unsigned long long lo = (unsigned long long)__builtin_bit_cast(unsigned, v[0]) | ((unsigned long long)__builtin_bit_cast(unsigned, v[1]) << 32);
+            const unsigned long long hi = (unsigned long long)__builtin_bit_cast(unsigned, v[2]) | ((unsigned long long)__builtin_bit_cast(unsigned, v[3]) << 32);
+            unsigned long long* dstp = (unsigned long long*)(rowp + d);
+            if (fused) {                                             // sc1: write-through
+                __hip_atomic_store(dstp, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q < HD / 4) __hip_atomic_store(dstp + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                dstp[0] = lo;
+                if (q < HD / 4) dstp[1] = hi;
             }
         }
-        const int ih = (i * inv_m) >> 8;
-        float* dstp = p.part + (((size_t)(head0 + ih) * p.max_pages + page_l) * LSK_ROWS + (i - ih * M)) * PSTRIDE + d;
-        if (fused) __hip_atomic_store(dstp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
-        else *dstp = v;
     }
     if (!fused) { LSK_TRACE_FLUSH(p, col * p.n_pages + page_l); return; }
     LSK_TRACE_POINT(4);                                           // partial stores issued
@@ -250,46 +294,97 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
     __syncthreads();
     LSK_TRACE_POINT(6);                                           // ticket returned
     if (!*s_last_p) { LSK_TRACE_FLUSH(p, col * p.n_pages + page_l); return; }
-    for (int e = tid; e < n_rows * (HD / 2); e += LSK_ATTN_THREADS) {
-        const int i = e / (HD / 2);
-        const int d = (e - i * (HD / 2)) * 2;          // two adjacent features per thread: one 32-bit store
-        const int ih = (i * inv_m) >> 8;
-        const int r = i - ih * M;
-        const int head = head0 + ih;
-        const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
-        const int n_pages = (base_pos + r) / LSK_ATTN_PAGE + 1;
-        float m = LSK_ATTN_NEG, l = 0.f, a0 = 0.f, a1 = 0.f;
-        for (int p0 = 0; p0 < n_pages; p0 += 8) {
-            float mo[8], lo[8], x0[8], x1[8];
+    // (two forms again: a feature pair per work item while that is one trip -- 64 items for a one-row pass --, a quad beyond: a 7-row
+    // verify pass is 224 items, one trip instead of two, its page partials fetched as three 8-byte sc1 loads per page)
+    if (n_rows * (HD / 2) <= LSK_ATTN_THREADS) {
+        for (int e = tid; e < n_rows * (HD / 2); e += LSK_ATTN_THREADS) {
+            const int i = e / (HD / 2);
+            const int d = (e - i * (HD / 2)) * 2;          // two adjacent features per thread: one 32-bit store
+            const int ih = (i * inv_m) >> 8;
+            const int r = i - ih * M;
+            const int head = head0 + ih;
+            const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
+            const int n_pages = (base_pos + r) / LSK_ATTN_PAGE + 1;
+            float m = LSK_ATTN_NEG, l = 0.f, a0 = 0.f, a1 = 0.f;
+            for (int p0 = 0; p0 < n_pages; p0 += 8) {
+                float mo[8], lo[8], x0[8], x1[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int pg = min(p0 + k, n_pages - 1);
-                const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
-                // (max, sum) and the two features are 8-byte aligned pairs (row stride (HD + 2) * 4 B, d even): one
-                // 64-bit sc1 load each instead of two 32-bit ones
-                const unsigned long long ml = __hip_atomic_load((const unsigned long long*)(src + HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long xx = __hip_atomic_load((const unsigned long long*)(src + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mo[k] = __builtin_bit_cast(float, (unsigned)ml);
-                lo[k] = __builtin_bit_cast(float, (unsigned)(ml >> 32));
-                x0[k] = __builtin_bit_cast(float, (unsigned)xx);
-                x1[k] = __builtin_bit_cast(float, (unsigned)(xx >> 32));
-            }
+                for (int k = 0; k < 8; ++k) {
+                    const int pg = min(p0 + k, n_pages - 1);
+                    const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
+                    // (max, sum) and the two features are 8-byte aligned pairs (row stride (HD + 2) * 4 B, d even): one
+                    // 64-bit sc1 load each instead of two 32-bit ones
+                    const unsigned long long ml = __hip_atomic_load((const unsigned long long*)(src + HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long xx = __hip_atomic_load((const unsigned long long*)(src + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mo[k] = __builtin_bit_cast(float, (unsigned)ml);
+                    lo[k] = __builtin_bit_cast(float, (unsigned)(ml >> 32));
+                    x0[k] = __builtin_bit_cast(float, (unsigned)xx);
+                    x1[k] = __builtin_bit_cast(float, (unsigned)(xx >> 32));
+                }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (p0 + k < n_pages) {
-                    const float mn = fmaxf(m, mo[k]);
-                    const float fa = __builtin_amdgcn_exp2f(m - mn);
-                    const float fb = __builtin_amdgcn_exp2f(mo[k] - mn);
-                    l = l * fa + lo[k] * fb;
-                    a0 = a0 * fa + x0[k] * fb;
-                    a1 = a1 * fa + x1[k] * fb;
-                    m = mn;
+                for (int k = 0; k < 8; ++k) {
+                    if (p0 + k < n_pages) {
+                        const float mn = fmaxf(m, mo[k]);
+                        const float fa = __builtin_amdgcn_exp2f(m - mn);
+                        const float fb = __builtin_amdgcn_exp2f(mo[k] - mn);
+                        l = l * fa + lo[k] * fb;
+                        a0 = a0 * fa + x0[k] * fb;
+                        a1 = a1 * fa + x1[k] * fb;
+                        m = mn;
+                    }
                 }
             }
+            const elem_t o0 = f2e(a0 / l), o1 = f2e(a1 / l);
+            const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
+            *(unsigned*)(p.out + (size_t)r * p.ldo + head * HD + d) = packed;
         }
-        const elem_t o0 = f2e(a0 / l), o1 = f2e(a1 / l);
-        const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
-        *(unsigned*)(p.out + (size_t)r * p.ldo + head * HD + d) = packed;
+    } else {
+        for (int e = tid; e < n_rows * (HD / 4); e += LSK_ATTN_THREADS) {
+            const int i = e / (HD / 4);
+            const int d = (e - i * (HD / 4)) * 4;
+            const int ih = (i * inv_m) >> 8;
+            const int r = i - ih * M;
+            const int head = head0 + ih;
+            const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
+            const int n_pages = (base_pos + r) / LSK_ATTN_PAGE + 1;
+            float m = LSK_ATTN_NEG, l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int p0 = 0; p0 < n_pages; p0 += 8) {
+                float mo[8], lo[8], x0[8], x1[8], x2[8], x3[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int pg = min(p0 + k, n_pages - 1);
+                    const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
+                    // (max, sum) and the features are 8-byte aligned pairs (row stride (HD + 2) * 4 B, d even)
+                    const unsigned long long ml = __hip_atomic_load((const unsigned long long*)(src + HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long xa = __hip_atomic_load((const unsigned long long*)(src + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long xb = __hip_atomic_load((const unsigned long long*)(src + d + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mo[k] = __builtin_bit_cast(float, (unsigned)ml);
+                    lo[k] = __builtin_bit_cast(float, (unsigned)(ml >> 32));
+                    x0[k] = __builtin_bit_cast(float, (unsigned)xa);
+                    x1[k] = __builtin_bit_cast(float, (unsigned)(xa >> 32));
+                    x2[k] = __builtin_bit_cast(float, (unsigned)xb);
+                    x3[k] = __builtin_bit_cast(float, (unsigned)(xb >> 32));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (p0 + k < n_pages) {
+                        const float mn = fmaxf(m, mo[k]);
+                        const float fa = __builtin_amdgcn_exp2f(m - mn);
+                        const float fb = __builtin_amdgcn_exp2f(mo[k] - mn);
+                        l = l * fa + lo[k] * fb;
+                        a0 = a0 * fa + x0[k] * fb;
+                        a1 = a1 * fa + x1[k] * fb;
+                        a2 = a2 * fa + x2[k] * fb;
+                        a3 = a3 * fa + x3[k] * fb;
+                        m = mn;
+                    }
+                }
+            }
+            const elem_t o0 = f2e(a0 / l), o1 = f2e(a1 / l), o2 = f2e(a2 / l), o3 = f2e(a3 / l);
+            const unsigned long long packed = (unsigned long long)__builtin_bit_cast(unsigned short, o0) | ((unsigned long long)__builtin_bit_cast(unsigned short, o1) << 16) |
+                                              ((unsigned long long)__builtin_bit_cast(unsigned short, o2) << 32) | ((unsigned long long)__builtin_bit_cast(unsigned short, o3) << 48);
+            *(unsigned long long*)(p.out + (size_t)r * p.ldo + head * HD + d) = packed;
+        }
     }
     if (tid == 0) __hip_atomic_store(p.counters + col, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef LSK_TRACE
