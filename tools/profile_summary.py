@@ -68,6 +68,9 @@ def main():
             "third digit) at 0.09-0.10 MFMA busy cycles per wave cycle -- weight streaming, as a <= 16-row product must be; a third of the wave cycles are",
             "parked on `s_waitcnt` / barriers and most of the rest are issue stalls behind the in-order weight ring (SQ_WAIT_INST_ANY), i.e. the kernels wait on",
             "HBM, not on arithmetic.  The prefill kernels (`lsk_gemm_big_kernel`) are the MFMA-shaped part (0.8-1.0)."]
+    note = os.path.join(prof, f"{tag}_profile_note.md")          # hand-written remarks of the round (e.g. what the profiler itself costs)
+    if os.path.exists(note):
+        out += ["", open(note).read().rstrip("\n")]
     open(os.path.join(prof, f"{tag}_profile_summary.md"), "w").write("\n".join(out) + "\n")
     print("\n".join(out[:24]))
 
