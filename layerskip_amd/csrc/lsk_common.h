@@ -131,7 +131,7 @@ struct GemmParams {
     unsigned wp_bytes;
     int N;                  // logical output features (rows of the nn.Linear weight)
     int n_tiles;            // ceil(N / 16)
-    int tiles_per_wg;       // <= 8 (<= 16 for SWIGLU: 8 gate/up pairs)
+    int tiles_per_wg;       // <= 8 (<= 16 for SWIGLU: 8 gate/up pairs; any number for EPI_HEAD when K is one chunk): set by launch_gemm
     const elem_t* norm_w;   // PRO_RMS gain [K]
     float eps;
     // EPI_F32
