@@ -25,7 +25,7 @@
 // kernel arguments in front of the parameter block: with -mllvm -amdgpu-kernarg-preload-count=14 (layerskip_amd/build.py) the
 // first 14 argument dwords are in SGPRs when the wave starts, instead of one scalar-memory round trip (~1 us on this chip next to
 // a weight stream, profiles/r03_kernel_timeline.md) later.  14 dwords: four pointers and six 32-bit words, two of each with a
-// meaning that depends on the kernel's (PRO, EPI) -- `lsk_gemm_hot_args` below packs them, `lsk_gemm_kernel` unpacks them.
+// meaning that depends on the kernel's (PRO, EPI) -- `GemmHotArgs` (bottom of this file) packs them, `lsk_gemm_kernel` unpacks them.
 // Everything else stays in the block and is read at the top of the kernel, under the rows' and the ring's flight time.
 struct GemmHot {
     const elem_t* x;        // = GemmParams::x, wp, ... (same meaning)
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const elem_t* x, 
 template <int PRO, int EPI>
 struct GemmHotArgs {
     const void* a2; const void* a3; int m_tpw; unsigned e0;
+    static_assert(!(PRO == PRO_RMS && EPI == EPI_RESID), "the norm gain and the residual pointer share an argument slot");
     explicit GemmHotArgs(const GemmParams& p) {
         a2 = (PRO == PRO_RMS) ? (const void*)p.norm_w : (EPI == EPI_RESID ? (const void*)p.h : nullptr);   // (no kernel is both)
         a3 = (EPI == EPI_QKV) ? (const void*)p.kv_len : nullptr;
