@@ -147,3 +147,18 @@ def test_kernel_resources_of_the_product_build():
     assert not spilled, spilled
     decode = {k: v["preload"] for k, v in kernels.items() if "lsk_gemm_kernel" in k or "lsk_attn_split_kernel" in k}
     assert len(decode) >= 20 and all(n == 14 for n in decode.values()), decode
+
+
+def test_the_timeline_instrumentation_still_builds():
+    """tools/kernel_timeline.py needs a -DLSK_TRACE build of the engine (in-kernel time stamps, lsk_common.h); the product build
+    compiles none of it, so only this test keeps it from rotting."""
+    import subprocess
+    import tempfile
+    from layerskip_amd import build
+    csrc = os.path.join(ROOT, "layerskip_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        proc = subprocess.run(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DLSK_TRACE", "--cuda-device-only", "-S", "-o", os.path.join(td, "x.s"),
+                               os.path.join(csrc, "lsk_engine.hip")], capture_output=True, text=True)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        text = open(os.path.join(td, "x.s")).read()
+    assert text.count("s_memrealtime") > 100          # the stamps are there
