@@ -120,7 +120,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the engine)"
     # LSK_BENCH_SAME_GPU=1 + LSK_BENCH_BACKEND=gloo: the multi-process path on a 1-GPU box
     backend = os.environ.get("LSK_BENCH_BACKEND", "nccl")
-    if os.environ.get("LSK_BENCH_SAME_GPU") == "1":
+    same_gpu = os.environ.get("LSK_BENCH_SAME_GPU") == "1"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if not same_gpu and torch.cuda.device_count() < local_world:
+        # launched by torchrun directly on a box with fewer GPUs than ranks: the same development-box mode as self_spawn's
+        same_gpu = True
+        backend = os.environ.get("LSK_BENCH_BACKEND", "gloo")
+    if same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -426,7 +432,8 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev, backend):
             "acceptance_rate": round(sum(acc) / len(acc), 4) if acc else None,
             "config": {"workload": f"{args.model} shape, exit_layer={E}, num_speculations={S}, {args.prompt_len}-token prompt, "
                                    f"{args.max_steps} new tokens, batch 1, greedy, random-init weights (late damping {args.late_damping})",
-                       "strategy": "self_speculative", "parallelism": f"pp{world}: layer ranges {part}, RCCL point-to-point"},
+                       "strategy": "self_speculative", "parallelism": f"pp{world}: layer ranges {part}, " + ("RCCL point-to-point" if backend == "nccl" else
+                                                                                                f"{backend} point-to-point, ranks SHARING one GPU (plumbing run)")},
             "pipeline": {**hop_stats[0],
                          "hops": [{"rank": r, "layers": list(part[r]), "hop_enqueue_ms": st.get("hop_enqueue_ms"), "hop_wait_ms": st.get("hop_wait_ms"),
                                    "blocks": st.get("hops")} for r, st in enumerate(hop_stats) if r > 0],
