@@ -135,10 +135,133 @@ __device__ __forceinline__ int block_argmax(float v, int idx, float* red, int* r
     return bi;
 }
 
+// The row held in REGISTERS (V <= 32 768: the llama2 vocabularies): thread t owns the 8 quads 4 (t + 1024 k) .. + 3, k < 8 -- the
+// same quads its Philox counters cover in the draw.  Every logit is read from memory once and its exponential computed once; the
+// ~35 bisection steps of the two filters are then compares and adds on registers plus one block reduction each (they were ~35
+// passes over a 128 KB row in L2, each recomputing the exponentials: ~40 us per draw).  Same thresholds, same draw.
+#define LSK_SAMPLE_QUADS 8
+__device__ __forceinline__ void lsk_sample_row_cached(const SampleParams& p, const int row, float* red, int* redi) {
+    const int tid = threadIdx.x;
+    const int V = p.vocab;
+    const float* x = p.logits + (size_t)row * p.ld;
+    const float it = p.inv_temperature;
+    float xv[LSK_SAMPLE_QUADS][4];
+    int key[LSK_SAMPLE_QUADS][4];                               // ordered 16-bit key; -1 = no such element (never counted)
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < LSK_SAMPLE_QUADS; ++k) {
+        const int i0 = 4 * (tid + LSK_SAMPLE_THREADS * k);
+        float4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (i0 + 3 < V) v = *(const float4*)(x + i0);          // rows start 16-byte aligned (ld is a multiple of 4 floats)
+        else {
+            if (i0 < V) v.x = x[i0];
+            if (i0 + 1 < V) v.y = x[i0 + 1];
+            if (i0 + 2 < V) v.z = x[i0 + 2];
+        }
+        xv[k][0] = v.x; xv[k][1] = v.y; xv[k][2] = v.z; xv[k][3] = v.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, xv[k][j]);
+    }
+    m = block_max(m, red);
+    const int key_max = lsk_key16(m);
+    float ev[LSK_SAMPLE_QUADS][4];                              // exp((x - max) / temperature); 0 where there is no element
+#pragma unroll
+    for (int k = 0; k < LSK_SAMPLE_QUADS; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool valid = 4 * (tid + LSK_SAMPLE_THREADS * k) + j < V;
+            key[k][j] = valid ? lsk_key16(xv[k][j]) : -1;
+            ev[k][j] = valid ? __expf((xv[k][j] - m) * it) : 0.f;
+        }
+    // ---- top-k: largest key K with count{key >= K} >= k ----
+    int K = 0;
+    if (p.top_k > 0 && p.top_k < V) {
+        int lo = 0, hi = key_max;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            float c = 0.f;
+#pragma unroll
+            for (int k = 0; k < LSK_SAMPLE_QUADS; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c += (key[k][j] >= mid) ? 1.f : 0.f;
+            c = block_sum(c, red);
+            if (c >= (float)p.top_k) lo = mid; else hi = mid - 1;
+        }
+        K = lo;
+    }
+    // ---- top-p on the top-k survivors: smallest key P >= K with mass{key > P} < top_p * Z ----
+    int P = K;
+    if (p.top_p < 1.0f) {
+        float z = 0.f;
+#pragma unroll
+        for (int k = 0; k < LSK_SAMPLE_QUADS; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z += (key[k][j] >= K) ? ev[k][j] : 0.f;
+        z = block_sum(z, red);
+        const float budget = p.top_p * z;
+        int lo = K, hi = key_max;
+        if (!(p.top_p > 0.f)) lo = key_max;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            float g = 0.f;
+#pragma unroll
+            for (int k = 0; k < LSK_SAMPLE_QUADS; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g += (key[k][j] > mid) ? ev[k][j] : 0.f;
+            g = block_sum(g, red);
+            if (g < budget) hi = mid; else lo = mid + 1;
+        }
+        P = lo;
+    }
+    // ---- normalise, write the probabilities, Gumbel-max draw ----
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < LSK_SAMPLE_QUADS; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z += (key[k][j] >= P) ? ev[k][j] : 0.f;
+    z = block_sum(z, red);
+    const float inv_z = 1.0f / z;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    float* po = p.probs_out + (size_t)row * p.ld;
+#pragma unroll
+    for (int k = 0; k < LSK_SAMPLE_QUADS; ++k) {
+        const int gq = tid + LSK_SAMPLE_THREADS * k;
+        if (4 * gq < V) {
+            unsigned int rnd[4];
+            lsk_philox4x32_10((unsigned int)gq, (unsigned int)(p.tag0 + row), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi, rnd);
+            float pr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = gq * 4 + j;
+                const bool keep = key[k][j] >= P;                // (-1 for i >= V: never kept)
+                pr[j] = keep ? ev[k][j] * inv_z : 0.f;
+                const float s = keep ? (xv[k][j] - m) * it + lsk_gumbel(rnd[j]) : -INFINITY;
+                if (s > best || (s == best && i < best_i)) { best = s; best_i = i; }
+            }
+            if (4 * gq + 3 < V) *(float4*)(po + 4 * gq) = float4{pr[0], pr[1], pr[2], pr[3]};
+            else
+                for (int j = 0; j < 4; ++j)
+                    if (4 * gq + j < V) po[4 * gq + j] = pr[j];
+        }
+    }
+    const int tok = block_argmax(best, best_i, red, redi);
+    if (tid == 0) p.tokens_out[row] = tok;
+    if (row == 0 && p.embed_dst != nullptr) {
+        const elem8* src = (const elem8*)(p.embed + (size_t)tok * p.hidden);
+        elem8* dst = (elem8*)p.embed_dst;
+        for (int i = tid; i < p.hidden / 8; i += LSK_SAMPLE_THREADS) dst[i] = src[i];
+    }
+}
+
 __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_kernel(const SampleParams p) {
     __shared__ float red[LSK_SAMPLE_WAVES];
     __shared__ int redi[LSK_SAMPLE_WAVES];
     const int row = blockIdx.x;
+    if (p.vocab <= 4 * LSK_SAMPLE_QUADS * LSK_SAMPLE_THREADS && (p.ld & 3) == 0) {
+        lsk_sample_row_cached(p, row, red, redi);
+        return;
+    }
     const int tid = threadIdx.x;
     const int V = p.vocab;
     const float* x = p.logits + (size_t)row * p.ld;
