@@ -469,6 +469,7 @@ int lsk_run_head_dev(lsk_engine* e, const elem_t* x, int m, float* logits, int l
     LSK_TRY(profile_pair(e, LSK_PROF_HEAD, m, (double)p.wp_bytes, &ea, &eb));
     LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, e->target_wgs, st, &grid, ea, eb)));
     if (grid > e->max_parts) return lsk_fail("internal: head grid %d > max_parts %d", grid, e->max_parts);
+    if (tokens_dev == nullptr) return 0;                         // sample=True: the logits rows are what the caller wants, nobody reads an argmax
     hipLaunchKernelGGL(lsk_argmax_finalize_kernel, dim3(m), dim3(embed_dst ? 256 : 64), 0, st, e->part_val, e->part_idx, grid, m, tokens_dev,
                        e->embed, e->cfg.hidden, e->cfg.vocab, embed_dst);
     HIP_OK(hipGetLastError());

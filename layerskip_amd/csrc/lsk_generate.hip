@@ -84,7 +84,7 @@ static int enqueue_step_body(lsk_engine* e, int P, int S, int E, int n_eos, int 
             if (sm == nullptr) {
                 LSK_TRY(lsk_run_head_dev(e, xr, 1, nullptr, 0, e->row_tokens + j + 1, st, xr + c.hidden));
             } else {
-                LSK_TRY(lsk_run_head_dev(e, xr, 1, sm->logits, sm->ld, e->verified, st));      // the argmax lands in `verified` and is ignored
+                LSK_TRY(lsk_run_head_dev(e, xr, 1, sm->logits, sm->ld, nullptr, st));          // logits only: the token is drawn, not maximised
                 LSK_TRY(launch_sample(e, sm->logits, sm->ld, 1, sm->temperature, sm->top_k, sm->top_p, sm->seed, sm->offset, j,
                                       e->row_tokens + j + 1, sm->p_draft + (size_t)j * sm->ld, xr + c.hidden, st));
             }
@@ -100,7 +100,7 @@ static int enqueue_step_body(lsk_engine* e, int P, int S, int E, int n_eos, int 
         hipLaunchKernelGGL(lsk_accept_kernel, dim3(1), dim3(64), 0, st, e->row_tokens + 1, e->verified, S, e->eos, n_eos, P, e->state, dres);
         HIP_OK(hipGetLastError());
     } else {
-        LSK_TRY(lsk_run_head_dev(e, e->hrow, S + 1, sm->logits, sm->ld, e->verified, st));
+        LSK_TRY(lsk_run_head_dev(e, e->hrow, S + 1, sm->logits, sm->ld, nullptr, st));
         LSK_TRY(launch_sample(e, sm->logits, sm->ld, S + 1, sm->temperature, sm->top_k, sm->top_p, sm->seed, sm->offset, LSK_TAG_VERIFY,
                               e->verified, sm->p_verify, nullptr, st));
         AcceptSampledParams ap{};
