@@ -28,6 +28,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LSK_SPW 16             // k-steps per wave per (tile, chunk) unit = depth of the weight ring
 #define LSK_ROWS 16
 #define LSK_ATTN_PAGE 128          // KV page size == keys per decode-attention workgroup
+#define LSK_SAMPLE_REG_VOCAB 32768  // sample=True: rows of up to this many logits live in one workgroup's registers (lsk_sample.h)
 
 __device__ __forceinline__ float e2f(elem_t v) { return (float)v; }
 __device__ __forceinline__ elem_t f2e(float v) { return (elem_t)v; }   // round-to-nearest-even

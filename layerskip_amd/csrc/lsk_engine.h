@@ -37,6 +37,14 @@ struct lsk_engine {
     elem_t* act = nullptr;        // [16][I]
     float* attn_part = nullptr;   // [n_heads][n_pages][16][hd + 2] split-KV partials
     int* attn_cnt = nullptr;      // [n_heads / HW] arrival tickets of the in-launch combine (self-resetting)
+    // sample=True on vocabularies of more than 32 768 entries (lsk_sample.h): per-row mass / count histograms over the 65 536 keys,
+    // row states, per-workgroup winners; all zero between draws; nullptr for smaller vocabularies (their rows live in registers)
+    unsigned long long* samp_hist = nullptr;
+    unsigned int* samp_cnt = nullptr;
+    void* samp_rows = nullptr;
+    unsigned long long* samp_coarse = nullptr;   // [17][256] | fine [17][256]: the two-level form (top_k == 0)
+    float* samp_part_val = nullptr;
+    int* samp_part_idx = nullptr;
     bool fused_attn = true;
     bool flash_prefill = true;    // prompt rows: one flash-shaped attention launch per layer instead of rows/16 decode launches
     elem_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]

@@ -36,7 +36,8 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
     size_t state, zero, block_table, row_tokens, verified, eos, result, bulk_ids, part_val, part_idx, hrow, hmsg, hbulk, qbuf,
-        attn, act, attn_part, attn_cnt, xn_bulk, q_bulk, attn_bulk, act_bulk, total;
+        attn, act, attn_part, attn_cnt, xn_bulk, q_bulk, attn_bulk, act_bulk, samp_hist, samp_cnt, samp_rows, samp_coarse, samp_part_val, samp_part_idx, total;
+    bool samp_big;
     int max_parts, n_pages;
 };
 
@@ -82,6 +83,15 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.q_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
     L.attn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
     L.act_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->intermediate);
+    // large-vocabulary sampling state (LSK_SAMPLE_BIG_VOCAB, lsk_sample.h): 17 rows x 65 536 keys
+    L.samp_big = c->vocab > LSK_SAMPLE_REG_VOCAB;
+    const size_t srows = LSK_MAX_ROWS + 1;
+    L.samp_hist = take(L.samp_big ? srows * 65536 * sizeof(unsigned long long) : 0);
+    L.samp_cnt = take(L.samp_big ? srows * 65536 * sizeof(unsigned int) : 0);
+    L.samp_rows = take(L.samp_big ? srows * 64 : 0);
+    L.samp_coarse = take(L.samp_big ? srows * 2 * 256 * sizeof(unsigned long long) : 0);
+    L.samp_part_val = take(L.samp_big ? srows * 64 * sizeof(float) : 0);
+    L.samp_part_idx = take(L.samp_big ? srows * 64 * sizeof(int) : 0);
     L.total = off;
     return L;
 }
@@ -163,6 +173,14 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->q_bulk = (elem_t*)(e->ws + L.q_bulk);
     e->attn_bulk = (elem_t*)(e->ws + L.attn_bulk);
     e->act_bulk = (elem_t*)(e->ws + L.act_bulk);
+    if (L.samp_big) {
+        e->samp_hist = (unsigned long long*)(e->ws + L.samp_hist);
+        e->samp_cnt = (unsigned int*)(e->ws + L.samp_cnt);
+        e->samp_rows = e->ws + L.samp_rows;
+        e->samp_coarse = (unsigned long long*)(e->ws + L.samp_coarse);
+        e->samp_part_val = (float*)(e->ws + L.samp_part_val);
+        e->samp_part_idx = (int*)(e->ws + L.samp_part_idx);
+    }
     e->kv_pool = (elem_t*)kv_pool;
     e->kv_half_elems = (size_t)cfg->max_ctx * cfg->n_kv_heads * cfg->head_dim;
     e->kv_layer_elems = 2 * e->kv_half_elems;
@@ -176,6 +194,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
     if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
     if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * (cfg->n_heads + 16));
+    if (err == hipSuccess && L.samp_big) err = hipMemset(e->samp_hist, 0, L.samp_part_val - L.samp_hist);   // histograms + row states
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 128, hipHostMallocDefault);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[0], hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[1], hipEventDisableTiming);

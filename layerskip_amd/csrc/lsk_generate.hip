@@ -54,7 +54,35 @@ static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, floa
     sp.off_lo = (unsigned int)offset; sp.off_hi = (unsigned int)(offset >> 32);
     sp.tag0 = tag0; sp.tokens_out = tokens_dev; sp.probs_out = probs;
     sp.embed = e->embed; sp.hidden = e->cfg.hidden; sp.embed_dst = embed_dst;
-    hipLaunchKernelGGL(lsk_sample_kernel, dim3(m), dim3(LSK_SAMPLE_THREADS), 0, st, sp);
+    if (sp.vocab <= LSK_SAMPLE_REG_VOCAB || e->samp_hist == nullptr || (ld & 3)) {
+        hipLaunchKernelGGL(lsk_sample_kernel, dim3(m), dim3(LSK_SAMPLE_THREADS), 0, st, sp);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    // large vocabularies: the row spread over ns workgroups, masses in a full-resolution histogram (lsk_sample.h)
+    SampleBigParams bp{};
+    bp.s = sp; bp.hist = e->samp_hist; bp.cnt = e->samp_cnt; bp.rows = (SampleRowState*)e->samp_rows;
+    bp.part_val = e->samp_part_val; bp.part_idx = e->samp_part_idx;
+    const int groups = (sp.vocab + 3) / 4;
+    bp.ns = (groups + LSK_SAMPLE_THREADS - 1) / LSK_SAMPLE_THREADS;
+    if (bp.ns > 64) bp.ns = 64;
+    if (m > LSK_MAX_ROWS + 1) return lsk_fail("launch_sample: %d rows", m);
+    const dim3 wide(bp.ns, m), one(1, m);
+    hipLaunchKernelGGL(lsk_sample_max_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, bp);
+    if (!(sp.top_k > 0 && sp.top_k < sp.vocab)) {               // no top-k (the default): the two-level form
+        SampleTwoLevelParams tp{};
+        tp.b = bp; tp.coarse = e->samp_coarse; tp.fine = e->samp_coarse + (size_t)(LSK_MAX_ROWS + 1) * 256;
+        hipLaunchKernelGGL(lsk_sample_coarse_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, tp);
+        hipLaunchKernelGGL(lsk_sample_fine_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, tp);
+        hipLaunchKernelGGL(lsk_sample_draw2_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, tp);
+        hipLaunchKernelGGL(lsk_sample_pick2_kernel, dim3(m), dim3(256), 0, st, tp);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(lsk_sample_hist_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, bp);
+    hipLaunchKernelGGL(lsk_sample_scan_kernel, one, dim3(LSK_SAMPLE_THREADS), 0, st, bp);
+    hipLaunchKernelGGL(lsk_sample_draw_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, bp);
+    hipLaunchKernelGGL(lsk_sample_pick_kernel, dim3(m), dim3(256), 0, st, bp);
     HIP_OK(hipGetLastError());
     return 0;
 }

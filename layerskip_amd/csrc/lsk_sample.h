@@ -258,7 +258,8 @@ __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_kernel(const Sa
     __shared__ float red[LSK_SAMPLE_WAVES];
     __shared__ int redi[LSK_SAMPLE_WAVES];
     const int row = blockIdx.x;
-    if (p.vocab <= 4 * LSK_SAMPLE_QUADS * LSK_SAMPLE_THREADS && (p.ld & 3) == 0) {
+    static_assert(4 * LSK_SAMPLE_QUADS * LSK_SAMPLE_THREADS == LSK_SAMPLE_REG_VOCAB, "register path capacity");
+    if (p.vocab <= LSK_SAMPLE_REG_VOCAB && (p.ld & 3) == 0) {
         lsk_sample_row_cached(p, row, red, redi);
         return;
     }
@@ -344,6 +345,506 @@ __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_kernel(const Sa
         elem8* dst = (elem8*)p.embed_dst;
         for (int i = tid; i < p.hidden / 8; i += LSK_SAMPLE_THREADS) dst[i] = src[i];
     }
+}
+
+// ---- large vocabularies (V > 32 768: the llama3 family) ------------------------------------------------------------------------
+// One workgroup per row was ~300 us per draw at V = 128 256 (126 logits per thread, re-read and re-exponentiated in each of ~20
+// passes, then a Philox + two-logarithm Gumbel per element on ONE CU).  Here a row is spread over `ns` workgroups and the filters
+// need no search: the logits are bf16-exact, so a row has at most 65 536 distinct values, and a FULL-RESOLUTION histogram of its
+// probability mass by key (one 64-bit fixed-point integer atomic per element: exp(..) * 2^40, exact and order-independent, hence
+// deterministic) holds everything both filters ask for.  Five small launches:
+//   max   (ns x rows)  row maximum by atomicMax on the ordered bit pattern
+//   hist  (ns x rows)  mass (and, for top-k, count) of every key
+//   scan  (1  x rows)  one thread per 64 keys: suffix sums -> K (top-k), Z, P (top-p), 1 / Z_kept; clears the histogram behind itself
+//   draw  (ns x rows)  probabilities written, Gumbel-max over the kept set per workgroup
+//   pick  (1  x rows)  the row's winner among the ns partials (lowest index on ties), embedding row of row 0's token
+// Same definitions of K and P as above (same kept set unless a mass comparison sits within 2^-40 of its budget), the same Philox
+// counters and the same Gumbel scores: the same draw.
+#define LSK_SAMPLE_KEYS 65536
+#define LSK_SAMPLE_FIX 1099511627776.0f                          // 2^40
+
+struct SampleRowState {     // one per row, in the engine's workspace; max_bits is zero between draws
+    unsigned int max_bits;  // ordered bit pattern of the row maximum
+    int K, P;
+    float m, inv_z;
+    int pad[11];
+};
+
+struct SampleBigParams {
+    SampleParams s;
+    unsigned long long* hist;   // [rows][65536] mass per key, zero between draws
+    unsigned int* cnt;          // [rows][65536] elements per key (top-k only), zero between draws
+    SampleRowState* rows;
+    float* part_val;            // [rows][ns] best Gumbel score of each workgroup ...
+    int* part_idx;              // ... and its index
+    int ns;
+};
+
+__device__ __forceinline__ unsigned int lsk_ordered_bits(float x) {
+    const unsigned int b = __builtin_bit_cast(unsigned int, x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float lsk_from_ordered_bits(unsigned int o) {
+    return __builtin_bit_cast(float, (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ float4 lsk_load_quad(const float* x, int gq, int V, float fill) {
+    float4 v = {fill, fill, fill, fill};
+    const int i0 = 4 * gq;
+    if (i0 + 3 < V) v = *(const float4*)(x + i0);
+    else {
+        if (i0 < V) v.x = x[i0];
+        if (i0 + 1 < V) v.y = x[i0 + 1];
+        if (i0 + 2 < V) v.z = x[i0 + 2];
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_max_kernel(const SampleBigParams p) {
+    __shared__ float red[LSK_SAMPLE_WAVES];
+    const int row = blockIdx.y, V = p.s.vocab;
+    const float* x = p.s.logits + (size_t)row * p.s.ld;
+    const int groups = (V + 3) >> 2;
+    float m = -INFINITY;
+    for (int gq = blockIdx.x * LSK_SAMPLE_THREADS + threadIdx.x; gq < groups; gq += p.ns * LSK_SAMPLE_THREADS) {
+        const float4 v = lsk_load_quad(x, gq, V, -INFINITY);
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomicMax(&p.rows[row].max_bits, lsk_ordered_bits(m));
+}
+
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_hist_kernel(const SampleBigParams p) {
+    const int row = blockIdx.y, V = p.s.vocab;
+    const float* x = p.s.logits + (size_t)row * p.s.ld;
+    const float m = lsk_from_ordered_bits(p.rows[row].max_bits);
+    const float it = p.s.inv_temperature;
+    const bool count = p.s.top_k > 0 && p.s.top_k < V;
+    unsigned long long* hist = p.hist + (size_t)row * LSK_SAMPLE_KEYS;
+    unsigned int* cnt = p.cnt + (size_t)row * LSK_SAMPLE_KEYS;
+    const int groups = (V + 3) >> 2;
+    for (int gq = blockIdx.x * LSK_SAMPLE_THREADS + threadIdx.x; gq < groups; gq += p.ns * LSK_SAMPLE_THREADS) {
+        const float4 v = lsk_load_quad(x, gq, V, 0.f);
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (4 * gq + j < V) {
+                const int key = lsk_key16(xs[j]);
+                const unsigned long long q = (unsigned long long)(__expf((xs[j] - m) * it) * LSK_SAMPLE_FIX);
+                atomicAdd(hist + key, q);
+                if (count) atomicAdd(cnt + key, 1u);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_scan_kernel(const SampleBigParams p) {
+    constexpr int BINS = LSK_SAMPLE_KEYS / LSK_SAMPLE_THREADS;   // 64 consecutive keys per thread
+    __shared__ unsigned long long tot_m[LSK_SAMPLE_THREADS];
+    __shared__ unsigned int tot_c[LSK_SAMPLE_THREADS];
+    __shared__ unsigned long long wave_m[LSK_SAMPLE_WAVES];
+    __shared__ unsigned int wave_c[LSK_SAMPLE_WAVES];
+    __shared__ int s_K, s_P;
+    __shared__ unsigned long long s_Z, s_Zkept;
+    const int row = blockIdx.y, tid = threadIdx.x, w = tid >> 6, V = p.s.vocab;
+    unsigned long long* hist = p.hist + (size_t)row * LSK_SAMPLE_KEYS + (size_t)tid * BINS;
+    unsigned int* cnt = p.cnt + (size_t)row * LSK_SAMPLE_KEYS + (size_t)tid * BINS;
+    const bool count = p.s.top_k > 0 && p.s.top_k < V;
+    const float m = lsk_from_ordered_bits(p.rows[row].max_bits);
+    const int key_max = lsk_key16(m);
+    unsigned long long own_m = 0;
+    unsigned int own_c = 0;
+    for (int b = 0; b < BINS; ++b) { own_m += hist[b]; if (count) own_c += cnt[b]; }
+    tot_m[tid] = own_m; tot_c[tid] = own_c;
+    if (tid == 0) { s_K = 0; s_P = 0; s_Z = 0; s_Zkept = 0; }
+    __syncthreads();
+    if (tid < LSK_SAMPLE_WAVES) {
+        unsigned long long a = 0; unsigned int c = 0;
+        for (int u = 0; u < 64; ++u) { a += tot_m[tid * 64 + u]; c += tot_c[tid * 64 + u]; }
+        wave_m[tid] = a; wave_c[tid] = c;
+    }
+    __syncthreads();
+    // mass / count of the keys ABOVE this thread's run
+    unsigned long long above_m = 0;
+    unsigned int above_c = 0;
+    for (int ww = w + 1; ww < LSK_SAMPLE_WAVES; ++ww) { above_m += wave_m[ww]; above_c += wave_c[ww]; }
+    for (int u = tid + 1; u < (w + 1) * 64; ++u) { above_m += tot_m[u]; above_c += tot_c[u]; }
+    const int key_lo = tid * BINS;
+    // ---- top-k: largest key K with count{key >= K} >= k ----
+    if (count && above_c < (unsigned int)p.s.top_k && (unsigned int)p.s.top_k <= above_c + own_c) {
+        unsigned int c = above_c;
+        int K = key_lo;
+        for (int b = BINS - 1; b >= 0; --b) { c += cnt[b]; if (c >= (unsigned int)p.s.top_k) { K = key_lo + b; break; } }
+        s_K = K;
+    }
+    __syncthreads();
+    const int K = s_K;
+    // ---- Z = mass{key >= K} ----
+    if (K >= key_lo && K < key_lo + BINS) {
+        unsigned long long z = above_m;
+        for (int b = BINS - 1; b >= K - key_lo; --b) z += hist[b];
+        s_Z = z;
+    }
+    __syncthreads();
+    // ---- top-p: smallest key P >= K with mass{key > P} < top_p * Z ----
+    int P = K;
+    if (p.s.top_p < 1.0f) {
+        if (!(p.s.top_p > 0.f)) {
+            P = key_max;                                          // keeps the maximum only
+        } else {
+            const double budget = (double)p.s.top_p * (double)s_Z;
+            if ((double)above_m < budget && budget <= (double)(above_m + own_m)) {      // the crossing lies in this thread's run
+                unsigned long long a = above_m;                   // mass{key > key_lo + b} while walking b downwards
+                int Pp = key_lo + BINS - 1;
+                for (int b = BINS - 1; b >= 0; --b) {
+                    if ((double)a < budget) Pp = key_lo + b; else break;
+                    a += hist[b];
+                }
+                s_P = Pp;
+            }
+            __syncthreads();
+            P = max(s_P, K);
+        }
+    }
+    // ---- Z_kept = mass{key >= P} ----
+    if (P >= key_lo && P < key_lo + BINS) {
+        unsigned long long z = above_m;
+        for (int b = BINS - 1; b >= P - key_lo; --b) z += hist[b];
+        s_Zkept = z;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        SampleRowState& r = p.rows[row];
+        r.K = K; r.P = P; r.m = m;
+        r.inv_z = 1.0f / ((float)s_Zkept * (1.0f / LSK_SAMPLE_FIX));
+        r.max_bits = 0;                                           // ready for the next draw
+    }
+    for (int b = 0; b < BINS; ++b) { hist[b] = 0; if (count) cnt[b] = 0; }     // ... and so is the histogram
+}
+
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_draw_kernel(const SampleBigParams p) {
+    __shared__ float red[LSK_SAMPLE_WAVES];
+    __shared__ int redi[LSK_SAMPLE_WAVES];
+    const int row = blockIdx.y, V = p.s.vocab;
+    const float* x = p.s.logits + (size_t)row * p.s.ld;
+    float* po = p.s.probs_out + (size_t)row * p.s.ld;
+    const SampleRowState r = p.rows[row];
+    const float it = p.s.inv_temperature;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    const int groups = (V + 3) >> 2;
+    for (int gq = blockIdx.x * LSK_SAMPLE_THREADS + threadIdx.x; gq < groups; gq += p.ns * LSK_SAMPLE_THREADS) {
+        const float4 v = lsk_load_quad(x, gq, V, 0.f);
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+        unsigned int rnd[4];
+        lsk_philox4x32_10((unsigned int)gq, (unsigned int)(p.s.tag0 + row), p.s.off_lo, p.s.off_hi, p.s.seed_lo, p.s.seed_hi, rnd);
+        float pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = gq * 4 + j;
+            const bool keep = i < V && lsk_key16(xs[j]) >= r.P;
+            const float zi = (xs[j] - r.m) * it;
+            pr[j] = keep ? __expf(zi) * r.inv_z : 0.f;
+            const float sc = keep ? zi + lsk_gumbel(rnd[j]) : -INFINITY;
+            if (sc > best || (sc == best && i < best_i)) { best = sc; best_i = i; }
+        }
+        if (4 * gq + 3 < V) *(float4*)(po + 4 * gq) = float4{pr[0], pr[1], pr[2], pr[3]};
+        else
+            for (int j = 0; j < 4; ++j)
+                if (4 * gq + j < V) po[4 * gq + j] = pr[j];
+    }
+    // the workgroup's winner (lowest index on ties)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w] = best; redi[w] = best_i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bv = red[0];
+        int bi = redi[0];
+        for (int i = 1; i < LSK_SAMPLE_WAVES; ++i)
+            if (red[i] > bv || (red[i] == bv && redi[i] < bi)) { bv = red[i]; bi = redi[i]; }
+        p.part_val[row * p.ns + blockIdx.x] = bv;
+        p.part_idx[row * p.ns + blockIdx.x] = bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void lsk_sample_pick_kernel(const SampleBigParams p) {
+    __shared__ int s_tok;
+    const int row = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float bv = p.part_val[row * p.ns];
+        int bi = p.part_idx[row * p.ns];
+        for (int i = 1; i < p.ns; ++i) {
+            const float v = p.part_val[row * p.ns + i];
+            const int ix = p.part_idx[row * p.ns + i];
+            if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+        }
+        p.s.tokens_out[row] = bi;
+        s_tok = bi;
+    }
+    if (row != 0 || p.s.embed_dst == nullptr) return;
+    __syncthreads();
+    const elem8* src = (const elem8*)(p.s.embed + (size_t)s_tok * p.s.hidden);
+    elem8* dst = (elem8*)p.s.embed_dst;
+    for (int i = threadIdx.x; i < p.s.hidden / 8; i += 256) dst[i] = src[i];
+}
+
+// ---- the same for top_k == 0 (the default) without 128 256 global atomics: two 256-bin levels, workgroup-private in LDS --------
+// (profile of the form above at llama3-8B: hist 42 us -- same-address 64-bit atomics from 32 workgroups serialise at the memory side --
+// and scan 85 us -- one workgroup walking 512 KB of mostly empty bins.)  Without top-k only ONE threshold is searched, and a coarse
+// histogram by the key's high byte says which 256 keys it lies among:
+//   max    as above
+//   coarse (ns x rows)  mass by key >> 8: LDS atomics in the workgroup, then <= 256 global atomics per workgroup
+//   fine   (ns x rows)  every workgroup walks the 256 coarse sums (Z, budget, the crossing bin cb), then mass by key & 255 of the
+//                       elements with key >> 8 == cb, the same way
+//   draw   (ns x rows)  every workgroup walks the 256 fine sums (P, Z_kept), then probabilities + Gumbel-max as above
+//   pick   as above; also clears the two levels and the row maximum
+struct SampleTwoLevelParams {
+    SampleBigParams b;
+    unsigned long long* coarse;     // [rows][256], zero between draws
+    unsigned long long* fine;       // [rows][256], zero between draws
+};
+
+__device__ __forceinline__ void lsk_lds_hist_flush(unsigned long long* h, unsigned long long* dst) {
+    __syncthreads();
+    if (threadIdx.x < 256 && h[threadIdx.x] != 0) atomicAdd(dst + threadIdx.x, h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_coarse_kernel(const SampleTwoLevelParams p) {
+    __shared__ unsigned long long h[256];
+    const SampleParams& s = p.b.s;
+    const int row = blockIdx.y, V = s.vocab;
+    const float* x = s.logits + (size_t)row * s.ld;
+    const float m = lsk_from_ordered_bits(p.b.rows[row].max_bits);
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int groups = (V + 3) >> 2;
+    for (int gq = blockIdx.x * LSK_SAMPLE_THREADS + threadIdx.x; gq < groups; gq += p.b.ns * LSK_SAMPLE_THREADS) {
+        const float4 v = lsk_load_quad(x, gq, V, 0.f);
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * gq + j < V) atomicAdd(&h[lsk_key16(xs[j]) >> 8], (unsigned long long)(__expf((xs[j] - m) * s.inv_temperature) * LSK_SAMPLE_FIX));
+    }
+    lsk_lds_hist_flush(h, p.coarse + (size_t)row * 256);
+}
+
+// Where a budget is crossed in 256 sums, by ONE WAVE (lane l owns sums 4 l .. 4 l + 3; exact integers, so every workgroup that
+// asks gets the same answer): with f(b) = above0 + the sums above b, the smallest b with f(b) < budget; the mass above THAT sum
+// and the total.  bin = -1: no sum crosses (budget <= above0, or > the total).  `tmp`: 64 words of LDS.  Call with the whole wave.
+struct SampleCross { int bin; unsigned long long above, total; };
+__device__ __forceinline__ SampleCross lsk_wave_cross256(const unsigned long long* sums, unsigned long long* tmp, unsigned long long above0,
+                                                         double budget) {
+    const int l = threadIdx.x & 63;
+    unsigned long long own[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { own[k] = sums[4 * l + k]; tot += own[k]; }
+    tmp[l] = tot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    unsigned long long above = above0, below = 0;
+    for (int u = 0; u < 64; ++u) {
+        const unsigned long long t = tmp[u];
+        if (u > l) above += t; else if (u < l) below += t;
+    }
+    SampleCross r;
+    r.total = above + tot + below - above0;
+    r.bin = -1; r.above = 0;
+    const bool mine = (double)above < budget && budget <= (double)(above + tot);
+    int bin = -1;
+    unsigned long long a = above, at = 0;
+    if (mine) {
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            if ((double)a < budget) { bin = 4 * l + k; at = a; }   // (f is non-increasing upwards: once it fails it fails below too)
+            a += own[k];
+        }
+    }
+    const unsigned long long who = __ballot(mine);
+    if (who != 0) {
+        const int src = __ffsll((long long)who) - 1;
+        r.bin = __shfl(bin, src, 64);
+        const unsigned int lo = __shfl((unsigned int)at, src, 64), hi = __shfl((unsigned int)(at >> 32), src, 64);
+        r.above = ((unsigned long long)hi << 32) | lo;
+    }
+    return r;
+}
+
+// mass of the sums >= `from` (one wave, as above)
+__device__ __forceinline__ unsigned long long lsk_wave_mass_from(const unsigned long long* sums, unsigned long long* tmp, int from) {
+    const int l = threadIdx.x & 63;
+    unsigned long long t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (4 * l + k >= from) t += sums[4 * l + k];
+    __builtin_amdgcn_wave_barrier();
+    tmp[l] = t;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    unsigned long long z = 0;
+    for (int u = 0; u < 64; ++u) z += tmp[u];
+    return z;
+}
+
+// The coarse level of a row: Z, and the high byte `cb` of the keys among which P lies with the mass above that byte (cb = -1: no
+// nucleus filter, P = 0).  One wave.
+struct SampleCoarse { int cb; unsigned long long above, Z; };
+__device__ __forceinline__ SampleCoarse lsk_sample_walk_coarse(const unsigned long long* c, unsigned long long* tmp, float top_p, int key_max) {
+    SampleCoarse r;
+    if (top_p < 1.0f && top_p > 0.f) {
+        // two sweeps: the total first (the budget is a fraction of it), then the crossing
+        const unsigned long long Z = lsk_wave_mass_from(c, tmp, 0);
+        const SampleCross x = lsk_wave_cross256(c, tmp, 0, (double)top_p * (double)Z);
+        r.Z = Z; r.cb = x.bin; r.above = x.above;
+    } else {
+        r.Z = lsk_wave_mass_from(c, tmp, 0);
+        r.cb = (top_p < 1.0f) ? (key_max >> 8) : -1;              // top_p <= 0: the maximum only, nothing lies above its byte
+        r.above = 0;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_fine_kernel(const SampleTwoLevelParams p) {
+    __shared__ unsigned long long c[256];
+    __shared__ unsigned long long h[256];
+    __shared__ unsigned long long tmp[64];
+    __shared__ int s_cb;
+    const SampleParams& s = p.b.s;
+    const int row = blockIdx.y, V = s.vocab;
+    const float* x = s.logits + (size_t)row * s.ld;
+    const float m = lsk_from_ordered_bits(p.b.rows[row].max_bits);
+    if (threadIdx.x < 256) { c[threadIdx.x] = p.coarse[(size_t)row * 256 + threadIdx.x]; h[threadIdx.x] = 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const SampleCoarse r = lsk_sample_walk_coarse(c, tmp, s.top_p, lsk_key16(m));
+        if (threadIdx.x == 0) s_cb = r.cb;
+    }
+    __syncthreads();
+    const int cb = s_cb;
+    if (cb < 0) return;
+    const int groups = (V + 3) >> 2;
+    for (int gq = blockIdx.x * LSK_SAMPLE_THREADS + threadIdx.x; gq < groups; gq += p.b.ns * LSK_SAMPLE_THREADS) {
+        const float4 v = lsk_load_quad(x, gq, V, 0.f);
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = lsk_key16(xs[j]);
+            if (4 * gq + j < V && (key >> 8) == cb)
+                atomicAdd(&h[key & 255], (unsigned long long)(__expf((xs[j] - m) * s.inv_temperature) * LSK_SAMPLE_FIX));
+        }
+    }
+    lsk_lds_hist_flush(h, p.fine + (size_t)row * 256);
+}
+
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_draw2_kernel(const SampleTwoLevelParams p) {
+    __shared__ unsigned long long c[256];
+    __shared__ unsigned long long f[256];
+    __shared__ unsigned long long tmp[64];
+    __shared__ float red[LSK_SAMPLE_WAVES];
+    __shared__ int redi[LSK_SAMPLE_WAVES];
+    __shared__ int s_P;
+    __shared__ float s_inv_z;
+    const SampleParams& s = p.b.s;
+    const int row = blockIdx.y, V = s.vocab;
+    const float* x = s.logits + (size_t)row * s.ld;
+    float* po = s.probs_out + (size_t)row * s.ld;
+    const float m = lsk_from_ordered_bits(p.b.rows[row].max_bits);
+    if (threadIdx.x < 256) { c[threadIdx.x] = p.coarse[(size_t)row * 256 + threadIdx.x]; f[threadIdx.x] = p.fine[(size_t)row * 256 + threadIdx.x]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int key_max = lsk_key16(m);
+        const SampleCoarse r = lsk_sample_walk_coarse(c, tmp, s.top_p, key_max);
+        int P = 0;
+        unsigned long long zk = r.Z;                              // mass{key >= P}
+        if (r.cb >= 0) {
+            if (!(s.top_p > 0.f)) {
+                P = key_max;
+                zk = lsk_wave_mass_from(f, tmp, key_max & 255);
+            } else {
+                const SampleCross x = lsk_wave_cross256(f, tmp, r.above, (double)s.top_p * (double)r.Z);
+                P = r.cb * 256 + (x.bin >= 0 ? x.bin : 255);
+                zk = r.above + lsk_wave_mass_from(f, tmp, P & 255);
+            }
+        }
+        if (threadIdx.x == 0) {
+            s_P = P;
+            s_inv_z = 1.0f / ((float)zk * (1.0f / LSK_SAMPLE_FIX));
+        }
+    }
+    __syncthreads();
+    const int P = s_P;
+    const float inv_z = s_inv_z, it = s.inv_temperature;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    const int groups = (V + 3) >> 2;
+    for (int gq = blockIdx.x * LSK_SAMPLE_THREADS + threadIdx.x; gq < groups; gq += p.b.ns * LSK_SAMPLE_THREADS) {
+        const float4 v = lsk_load_quad(x, gq, V, 0.f);
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+        unsigned int rnd[4];
+        lsk_philox4x32_10((unsigned int)gq, (unsigned int)(s.tag0 + row), s.off_lo, s.off_hi, s.seed_lo, s.seed_hi, rnd);
+        float pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = gq * 4 + j;
+            const bool keep = i < V && lsk_key16(xs[j]) >= P;
+            const float zi = (xs[j] - m) * it;
+            pr[j] = keep ? __expf(zi) * inv_z : 0.f;
+            const float sc = keep ? zi + lsk_gumbel(rnd[j]) : -INFINITY;
+            if (sc > best || (sc == best && i < best_i)) { best = sc; best_i = i; }
+        }
+        if (4 * gq + 3 < V) *(float4*)(po + 4 * gq) = float4{pr[0], pr[1], pr[2], pr[3]};
+        else
+            for (int j = 0; j < 4; ++j)
+                if (4 * gq + j < V) po[4 * gq + j] = pr[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w] = best; redi[w] = best_i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bv = red[0];
+        int bi = redi[0];
+        for (int i = 1; i < LSK_SAMPLE_WAVES; ++i)
+            if (red[i] > bv || (red[i] == bv && redi[i] < bi)) { bv = red[i]; bi = redi[i]; }
+        p.b.part_val[row * p.b.ns + blockIdx.x] = bv;
+        p.b.part_idx[row * p.b.ns + blockIdx.x] = bi;
+    }
+}
+
+// pick for the two-level form: the winner, then the row's state back to zero
+__global__ __launch_bounds__(256) void lsk_sample_pick2_kernel(const SampleTwoLevelParams p) {
+    __shared__ int s_tok;
+    const SampleBigParams& b = p.b;
+    const int row = blockIdx.x;
+    p.coarse[(size_t)row * 256 + threadIdx.x] = 0;
+    p.fine[(size_t)row * 256 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        float bv = b.part_val[row * b.ns];
+        int bi = b.part_idx[row * b.ns];
+        for (int i = 1; i < b.ns; ++i) {
+            const float v = b.part_val[row * b.ns + i];
+            const int ix = b.part_idx[row * b.ns + i];
+            if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+        }
+        b.s.tokens_out[row] = bi;
+        b.rows[row].max_bits = 0;
+        s_tok = bi;
+    }
+    if (row != 0 || b.s.embed_dst == nullptr) return;
+    __syncthreads();
+    const elem8* src = (const elem8*)(b.s.embed + (size_t)s_tok * b.s.hidden);
+    elem8* dst = (elem8*)b.s.embed_dst;
+    for (int i = threadIdx.x; i < b.s.hidden / 8; i += 256) dst[i] = src[i];
 }
 
 struct AcceptSampledParams {

@@ -50,6 +50,49 @@ def test_sample_rows_matches_the_model_draw_for_draw(gpu_device, idx):
     eng.close()
 
 
+@pytest.mark.parametrize("temperature,top_k,top_p", [(0.6, 0, 0.9), (1.0, 50, 0.95), (0.8, 0, 1.0), (0.7, 400, 0.5)])
+def test_sample_rows_of_a_128k_vocabulary_match_the_model(gpu_device, temperature, top_k, top_p):
+    """The llama3 vocabulary (128 256 logits per row) takes the multi-workgroup form of the sampler -- row maximum, a full-resolution
+    mass histogram over the 65 536 keys, one scan for K / Z / P, per-workgroup Gumbel-max, pick -- against the same model as the
+    one-workgroup form: the kept set, the probabilities and the draws; and the histogram must be clean again after every draw
+    (the second and third draws of the loop would show a leftover)."""
+    from layerskip_amd import synthetic
+    from layerskip_amd.engine import HipEngine
+    from oracle import sampling_oracle as so
+    cfg = synthetic.make_config("slice-1B")
+    assert cfg.vocab_size > 32768
+    model = synthetic.build_model(cfg, seed=0, exit_layer=2, late_damping=0.1, dtype=torch.bfloat16, device=gpu_device, gen_device=gpu_device)
+    eng = HipEngine(model, max_ctx=256, max_prompt=32)
+    g = torch.Generator().manual_seed(77)
+    V = cfg.vocab_size
+    rows = torch.stack([(torch.randn(V, generator=g) * 2.0), (torch.randn(V, generator=g) * 3.5 - 1.0), (torch.randn(V, generator=g) * 0.7)])
+    rows = rows.to(torch.bfloat16).float()                   # logits are bf16-exact, as the lm_head produces them
+    rows[1, 777] = rows[1].max() + 4.0                        # one row with a dominant token
+    ld = (V + 3) // 4 * 4
+    logits = torch.zeros(3, ld, dtype=torch.float32)
+    logits[:, :V] = rows
+    logits = logits.to(gpu_device)
+    rows_np = rows.numpy()
+    warped = [so.device_warp(rows_np[r], temperature, top_k, top_p) for r in range(3)]
+    mismatches = total = 0
+    for offset in range(6):
+        toks, probs = eng.sample_rows(logits, temperature, top_k, top_p, seed=99, offset=offset, tag0=3)
+        toks, probs = toks.cpu().tolist(), probs.cpu().numpy()
+        for r in range(3):
+            keep, want_probs = warped[r]
+            assert ((probs[r, :V] > 0) == (want_probs > 0)).all(), (r, offset, int((probs[r, :V] > 0).sum()), int(keep.sum()))
+            assert np.allclose(probs[r, :V], want_probs, rtol=0, atol=2e-6)
+            x = rows_np[r]
+            z = ((x - x.max()) * np.float32(1.0 / temperature)).astype(np.float32)
+            u = so.device_uniforms(V, 3 + r, 99, offset)
+            score = np.where(keep, z.astype(np.float64) - np.log(-np.log(u.astype(np.float64))), -np.inf)
+            assert want_probs[toks[r]] > 0
+            total += 1
+            mismatches += int(toks[r] != int(np.argmax(score)))
+    assert mismatches <= 1, (mismatches, total)
+    eng.close()
+
+
 def test_accept_sampled_kernel_matches_the_model(gpu_device):
     import lsk_test_lib
     from oracle import sampling_oracle as so
