@@ -17,6 +17,9 @@ What is restated (deterministic parts; the random draws are inputs):
                         (self_speculation_generator.py:191-199): draft i is kept when u_i < min(1, q(x_i) / p(x_i));
                         at the first rejection the verified token is drawn from the residual distribution; when all
                         drafts are kept the extra token is the one sampled from the last verify row.
+  * device_*          : models of the DEVICE kernels (lsk_sample.h) -- their thresholds in the 16-bit key space, their Philox
+                        stream, their Gumbel-max draw -- so that kernel and model can be compared draw for draw;
+                        device_warp_histogram restates the large-vocabulary form (exact integer mass histograms).
 Parity is pinned by oracle/make_sampling_golden.py: vectors produced by the UNMODIFIED reference functions in the
 build container, stored under tests/golden/sampling/, checked by tests/test_sampling_oracle.py.
 """
@@ -165,6 +168,68 @@ def device_warp(logits: np.ndarray, temperature: float, top_k: int, top_p: float
     keep = keys >= P
     probs = np.where(keep, e, np.float32(0.0)).astype(np.float32)
     return keep, (probs / probs.sum(dtype=np.float32)).astype(np.float32)
+
+
+def device_warp_histogram(logits: np.ndarray, temperature: float, top_k: int, top_p: float):
+    """(kept mask, probabilities, P) as the LARGE-VOCABULARY form of the device sampler computes them (lsk_sample.h, V > 32 768):
+    no search -- the probability mass of every key as a 64-bit fixed-point integer (exp x 2^40, truncated), exact sums, and
+    for top_k == 0 the two 256-bin levels (by the key's high byte, then the low byte inside the byte where the budget is crossed);
+    with top-k the full-resolution histogram.  The SAME definitions of K and P as device_warp: the two agree unless a mass
+    comparison sits within rounding of its budget (tests/test_sampling_oracle.py measures how often)."""
+    x = logits.astype(np.float32)
+    v = x.shape[0]
+    keys = key16(x)
+    m = x.max()
+    e = np.exp(((x - m) * np.float32(1.0 / temperature)).astype(np.float32)).astype(np.float32)
+    q = (e.astype(np.float64) * 2.0 ** 40).astype(np.uint64)          # exact: a float32 times a power of two, truncated
+    key_max = int(keys.max())
+    mass = np.zeros(65536, dtype=np.uint64)
+    np.add.at(mass, keys, q)
+    K = 0
+    if 0 < top_k < v:
+        cnt = np.bincount(keys, minlength=65536)
+        above = np.cumsum(cnt[::-1])[::-1]                            # count{key >= k}
+        K = int(np.nonzero(above >= top_k)[0].max())
+    P = K
+    if top_p < 1.0:
+        if not top_p > 0.0:
+            P = key_max
+        elif 0 < top_k < v:
+            Z = int(mass[K:].sum(dtype=np.uint64))
+            budget = float(np.float32(top_p)) * float(Z)
+            above = 0                                                 # mass{key > P} walking P downwards
+            P = 65535
+            for c in range(65535, -1, -1):
+                if float(above) < budget:
+                    P = c
+                else:
+                    break
+                above += int(mass[c])
+            P = max(P, K)
+        else:
+            coarse = mass.reshape(256, 256).sum(axis=1, dtype=np.uint64)
+            Z = int(coarse.sum(dtype=np.uint64))
+            budget = float(np.float32(top_p)) * float(Z)
+            above, cb = 0, -1
+            for b in range(255, -1, -1):
+                if float(above) < budget <= float(above + int(coarse[b])):
+                    cb = b
+                    break
+                above += int(coarse[b])
+            assert cb >= 0
+            fine = mass[cb * 256:(cb + 1) * 256]
+            a, P = above, cb * 256 + 255
+            for b in range(255, -1, -1):
+                if float(a) < budget:
+                    P = cb * 256 + b
+                else:
+                    break
+                a += int(fine[b])
+    keep = keys >= P
+    zk = int(mass[P:].sum(dtype=np.uint64))
+    inv_z = np.float32(1.0) / (np.float32(zk) * np.float32(2.0 ** -40))
+    probs = np.where(keep, e * inv_z, np.float32(0.0)).astype(np.float32)
+    return keep, probs, P
 
 
 def device_sample_row(logits: np.ndarray, temperature: float, top_k: int, top_p: float, seed: int, offset: int, tag: int):

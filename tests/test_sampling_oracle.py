@@ -161,3 +161,28 @@ def test_device_accept_is_the_reference_loop():
     pd = [so.probabilities(rng.normal(size=v).astype(np.float32)) for _ in range(3)]
     n, ntd, _ = so.device_accept([5, 9, 7], [5, 9, 7, 1], pd, pd + [pd[0]], eos=[9], seed=1, offset=0)
     assert ntd == 2 and n == 2
+
+
+@pytest.mark.parametrize("vocab,top_k", [(40000, 0), (128256, 0), (50000, 64), (2000, 0)])
+def test_the_histogram_form_of_the_device_sampler_keeps_the_same_set(vocab, top_k):
+    """oracle.device_warp_histogram (how lsk_sample.h treats vocabularies of more than 32 768 entries: exact integer masses per key,
+    two 256-bin levels or a full histogram, no search) against oracle.device_warp (thresholds by bisection over float sums): the same
+    K / P definitions, so the same kept set and the same probabilities -- on random rows of several shapes, a row with a dominant token,
+    a row of many exact ties, and the extreme settings of top_p."""
+    rng = np.random.default_rng(vocab + top_k)
+    import torch
+    rows = []
+    for scale, shift in ((2.0, 0.0), (4.0, -1.0), (0.5, 3.0)):
+        r = torch.tensor(rng.standard_normal(vocab) * scale + shift).to(torch.bfloat16).float().numpy()
+        rows.append(r)
+    dom = rows[0].copy(); dom[17] = dom.max() + 6.0; rows.append(dom)
+    ties = np.round(rows[1] * 2) / 2; rows.append(torch.tensor(ties).to(torch.bfloat16).float().numpy())
+    checked = 0
+    for x in rows:
+        for temperature, top_p in ((0.6, 0.9), (1.0, 0.5), (0.8, 0.999), (1.3, 0.05), (0.7, 1.0), (0.9, 0.0)):
+            keep, probs = so.device_warp(x, temperature, top_k, top_p)
+            keep_h, probs_h, _ = so.device_warp_histogram(x, temperature, top_k, top_p)
+            assert (keep == keep_h).all(), (vocab, temperature, top_p, int(keep.sum()), int(keep_h.sum()))
+            assert np.allclose(probs, probs_h, rtol=0, atol=2e-6)
+            checked += 1
+    assert checked == 30
