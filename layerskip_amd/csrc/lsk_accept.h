@@ -90,11 +90,16 @@ __global__ void lsk_pipeline_pack_kernel(const elem_t* __restrict__ hrow, const 
     for (int i = threadIdx.x; i < hidden / 8; i += blockDim.x) dst[i] = src[i];
 }
 
-// a late rank: the rollback the header carries, applied on the device (the host only keeps an upper bound)
-__global__ void lsk_pipeline_apply_kernel(const elem_t* __restrict__ msg, StepState* st) {
-    const int* hdr = (const int*)msg;
+// a late rank: the rollback the header carries, applied on the device (the host only keeps an upper bound).  The host sized this
+// step's attention pages and bounds checks from `kv_bound`: a header length outside [0, kv_bound] would make the layers behind this
+// kernel read or write KV outside what was launched, so it is NOT applied and the header is defaced (magic word cleared) -- the host
+// raises when it reads the words, exactly as for a message without a header.
+__global__ void lsk_pipeline_apply_kernel(elem_t* __restrict__ msg, StepState* st, int kv_bound) {
+    int* hdr = (int*)msg;
     if (hdr[LSK_HDR_MAGIC] != LSK_HDR_MAGIC_VALUE) return;     // not a header: the host raises when it reads the words
-    st->kv_len = hdr[LSK_HDR_KV];
+    const int kv = hdr[LSK_HDR_KV];
+    if (kv < 0 || kv > kv_bound) { hdr[LSK_HDR_MAGIC] = 0; return; }
+    st->kv_len = kv;
 }
 
 // the last rank: acceptance straight from the header's drafts and its own argmaxes; the <= 96-byte result goes back to rank 0

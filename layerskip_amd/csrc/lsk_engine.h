@@ -45,6 +45,7 @@ struct lsk_engine {
     unsigned long long* samp_coarse = nullptr;   // [17][256] | fine [17][256]: the two-level form (top_k == 0)
     float* samp_part_val = nullptr;
     int* samp_part_idx = nullptr;
+    size_t samp_state_bytes = 0;                 // histograms + row states from samp_hist on: what must be zero between draws
     bool fused_attn = true;
     bool flash_prefill = true;    // prompt rows: one flash-shaped attention launch per layer instead of rows/16 decode launches
     elem_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]

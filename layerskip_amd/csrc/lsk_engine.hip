@@ -180,6 +180,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
         e->samp_coarse = (unsigned long long*)(e->ws + L.samp_coarse);
         e->samp_part_val = (float*)(e->ws + L.samp_part_val);
         e->samp_part_idx = (int*)(e->ws + L.samp_part_idx);
+        e->samp_state_bytes = L.samp_part_val - L.samp_hist;
     }
     e->kv_pool = (elem_t*)kv_pool;
     e->kv_half_elems = (size_t)cfg->max_ctx * cfg->n_kv_heads * cfg->head_dim;
@@ -194,7 +195,7 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
     if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
     if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * (cfg->n_heads + 16));
-    if (err == hipSuccess && L.samp_big) err = hipMemset(e->samp_hist, 0, L.samp_part_val - L.samp_hist);   // histograms + row states
+    if (err == hipSuccess && L.samp_big) err = hipMemset(e->samp_hist, 0, e->samp_state_bytes);   // histograms + row states
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 128, hipHostMallocDefault);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[0], hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[1], hipEventDisableTiming);

@@ -45,6 +45,17 @@ struct StepSampling {
     int ld;
 };
 
+// The large-vocabulary draw is a SEQUENCE of launches that hand histograms, row maxima and row states to each other and leave them zero
+// for the next draw (the last kernel of the sequence clears what the others filled).  If a launch of the sequence fails, the ones
+// behind it never run and the state stays dirty -- every later draw would silently use wrong masses.  So a failed sequence zeroes
+// the whole state before the error is returned.
+static int sample_sequence_status(lsk_engine* e, hipStream_t st) {
+    const hipError_t err = hipGetLastError();
+    if (err == hipSuccess) return 0;
+    if (e->samp_hist != nullptr && e->samp_state_bytes) (void)hipMemsetAsync(e->samp_hist, 0, e->samp_state_bytes, st);
+    return lsk_fail("sample=True: a launch of the draw sequence failed: %s (sampling state cleared)", hipGetErrorString(err));
+}
+
 static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, float temperature, int top_k, float top_p, uint64_t seed,
                          uint64_t offset, int tag0, int* tokens_dev, float* probs, elem_t* embed_dst, hipStream_t st) {
     SampleParams sp{};
@@ -76,15 +87,13 @@ static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, floa
         hipLaunchKernelGGL(lsk_sample_fine_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, tp);
         hipLaunchKernelGGL(lsk_sample_draw2_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, tp);
         hipLaunchKernelGGL(lsk_sample_pick2_kernel, dim3(m), dim3(256), 0, st, tp);
-        HIP_OK(hipGetLastError());
-        return 0;
+        return sample_sequence_status(e, st);
     }
     hipLaunchKernelGGL(lsk_sample_hist_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, bp);
     hipLaunchKernelGGL(lsk_sample_scan_kernel, one, dim3(LSK_SAMPLE_THREADS), 0, st, bp);
     hipLaunchKernelGGL(lsk_sample_draw_kernel, wide, dim3(LSK_SAMPLE_THREADS), 0, st, bp);
     hipLaunchKernelGGL(lsk_sample_pick_kernel, dim3(m), dim3(256), 0, st, bp);
-    HIP_OK(hipGetLastError());
-    return 0;
+    return sample_sequence_status(e, st);
 }
 
 // Enqueue every kernel of ONE speculation step plus the copy of its result block into pinned slot `slot`.
@@ -484,7 +493,7 @@ extern "C" int lsk_pipeline_pack(lsk_engine* e, int32_t go, int32_t prompt_len, 
 
 extern "C" int lsk_pipeline_apply(lsk_engine* e, int32_t kv_bound, void* stream) {
     if (!e || kv_bound < 0 || kv_bound > e->cfg.max_ctx) return lsk_fail("lsk_pipeline_apply: context bound %d out of range", kv_bound);
-    hipLaunchKernelGGL(lsk_pipeline_apply_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->hmsg, e->state);
+    hipLaunchKernelGGL(lsk_pipeline_apply_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->hmsg, e->state, kv_bound);
     HIP_OK(hipGetLastError());
     e->kv_len_host = kv_bound;        // an UPPER bound is all the host side needs (bounds checks, attention pages to launch)
     e->next_token_host = -1;

@@ -69,11 +69,19 @@ __host__ __device__ inline void lsk_philox4x32_10(unsigned int c0, unsigned int 
 // would be drawn regardless of its probability)
 __host__ __device__ inline float lsk_u01(unsigned int x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
-// ordered 16-bit key of a float (monotone in the value at bf16 resolution)
+// ordered 16-bit key of a logit: monotone in the value and EXACT at the model dtype's resolution (the logits were rounded to it by the
+// lm_head epilogue), so that equal keys are equal logits and the thresholds act on the same sets as the reference's warpers.
+// bf16: the sign-folded upper half of the fp32 pattern.  fp16 (-DLSK_ELEM_F16): the sign-folded fp16 pattern itself -- the upper half
+// of the fp32 pattern keeps only 7 of fp16's 10 mantissa bits and would merge up to 8 distinct logits into one key.
 __host__ __device__ inline int lsk_key16(float x) {
+#ifdef LSK_ELEM_F16
+    const unsigned int k = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)x);      // exact: x is an fp16 value
+    return (int)((k & 0x8000u) ? (~k & 0xFFFFu) : (k | 0x8000u));
+#else
     const unsigned int b = __builtin_bit_cast(unsigned int, x);
     const unsigned int k = b >> 16;
     return (int)((b & 0x80000000u) ? (~k & 0xFFFFu) : (k | 0x8000u));
+#endif
 }
 
 __device__ __forceinline__ float lsk_gumbel(unsigned int bits) { return -__logf(-__logf(lsk_u01(bits))); }
@@ -245,7 +253,9 @@ __device__ __forceinline__ void lsk_sample_row_cached(const SampleParams& p, con
                     if (4 * gq + j < V) po[4 * gq + j] = pr[j];
         }
     }
-    const int tok = block_argmax(best, best_i, red, redi);
+    // a NaN row leaves no score above -inf (best_i stays 0x7fffffff): clamp like the greedy finalize kernel does, so that neither the
+    // stored token nor the embedding gather below can leave the vocabulary
+    const int tok = min(max(block_argmax(best, best_i, red, redi), 0), p.vocab - 1);
     if (tid == 0) p.tokens_out[row] = tok;
     if (row == 0 && p.embed_dst != nullptr) {
         const elem8* src = (const elem8*)(p.embed + (size_t)tok * p.hidden);
@@ -338,7 +348,9 @@ __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_sample_kernel(const Sa
             }
         }
     }
-    const int tok = block_argmax(best, best_i, red, redi);
+    // a NaN row leaves no score above -inf (best_i stays 0x7fffffff): clamp like the greedy finalize kernel does, so that neither the
+    // stored token nor the embedding gather below can leave the vocabulary
+    const int tok = min(max(block_argmax(best, best_i, red, redi), 0), p.vocab - 1);
     if (tid == 0) p.tokens_out[row] = tok;
     if (row == 0 && p.embed_dst != nullptr) {
         const elem8* src = (const elem8*)(p.embed + (size_t)tok * p.hidden);
@@ -583,6 +595,7 @@ __global__ __launch_bounds__(256) void lsk_sample_pick_kernel(const SampleBigPar
             const int ix = p.part_idx[row * p.ns + i];
             if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
         }
+        bi = min(max(bi, 0), p.s.vocab - 1);          // a NaN row: no partial ever beat -inf (index 0x7fffffff)
         p.s.tokens_out[row] = bi;
         s_tok = bi;
     }
@@ -836,6 +849,7 @@ __global__ __launch_bounds__(256) void lsk_sample_pick2_kernel(const SampleTwoLe
             const int ix = b.part_idx[row * b.ns + i];
             if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
         }
+        bi = min(max(bi, 0), b.s.vocab - 1);          // a NaN row: no partial ever beat -inf (index 0x7fffffff)
         b.s.tokens_out[row] = bi;
         b.rows[row].max_bits = 0;
         s_tok = bi;

@@ -66,6 +66,12 @@ class HipEngine:
                  target_wgs: int = 0, layer_range: Optional[Sequence[int]] = None, release_weights: bool = False):
         cfg = model.config
         weight = model.model.embed_tokens.weight
+        dmap = getattr(model, "hf_device_map", None)
+        if dmap and len(set(dmap.values())) > 1:
+            # the reference's multi-GPU form (generate.py:59-64): ONE process, layers spread by accelerate hooks
+            raise _lib.LskError("this model was spread over several devices by device_map='auto'; the engine wants one process per GPU: "
+                                "launch the driver under torchrun (every rank loads its own layer range, layerskip_amd/checkpoint.py) "
+                                "or load the model on one device")
         if weight.device.type != "cuda":
             raise _lib.LskError("HipEngine needs the model on a HIP device (model.to('cuda')); there is no CPU path")
         if weight.dtype == torch.bfloat16:

@@ -144,20 +144,26 @@ class PipelineSpeculativeDecoder:
         makes the late ranks run one block on stale rows), and all ranks learn whether all of them could."""
         be = self.be
         meta = torch.zeros(4 + _MAX_EOS, dtype=torch.int64)
-        if self.rank == 0:
+        if self.rank == 0 and prompt_ids is None:
+            meta[0] = -1                      # shutdown(): the serve loops of the other ranks end
+        elif self.rank == 0:
             eos = [int(t) for t in eos_token_ids if t is not None and 0 <= int(t) < be.vocab]
-            if len(eos) > _MAX_EOS:
-                raise ValueError(f"{len(eos)} eos token ids; at most {_MAX_EOS}")
+            # (too many eos ids: the COUNT travels, so that the error below is raised on every rank through the agreement --
+            # raising here would leave the other ranks waiting in the broadcast)
             meta[:4] = torch.tensor([len(prompt_ids), S, max_steps, len(eos)])
-            meta[4:4 + len(eos)] = torch.tensor(eos, dtype=torch.int64)
+            meta[4:4 + min(len(eos), _MAX_EOS)] = torch.tensor(eos[:_MAX_EOS], dtype=torch.int64)
         if self.world > 1:
             meta = meta.to(self.dev)
             dist.broadcast(meta, src=0, group=self.group)
             meta = meta.cpu()
         P, S, max_steps, n_eos = (int(v) for v in meta[:4].tolist())
-        eos = [int(v) for v in meta[4:4 + n_eos].tolist()]
+        if P == -1:
+            return None
+        eos = [int(v) for v in meta[4:4 + min(n_eos, _MAX_EOS)].tolist()]
         err = None
         try:
+            if n_eos > _MAX_EOS:
+                raise ValueError(f"{n_eos} eos token ids; at most {_MAX_EOS}")
             if S + 1 > _MAX_ROWS:
                 raise ValueError("num_speculations too large for the 16-row verify block")
             if max_steps < 1 or P < 1:
@@ -231,6 +237,7 @@ class PipelineSpeculativeDecoder:
         if P > 1:
             self._rows_out(BUF_BULK, 0, P - 1, 1)
         self._rows_out(BUF_MSG, 0, self._S + 2, 1)
+        self._inflight += 1                        # the last rank answers every message with one result block
         return None
 
     def _result(self, local) -> List[int]:
@@ -238,18 +245,71 @@ class PipelineSpeculativeDecoder:
             return [int(v) for v in local[:_RES_WORDS].tolist()]
         t = torch.zeros(_RES_WORDS, dtype=torch.int32, device=self.dev)
         dist.recv(t, src=self.world - 1, group=self.group)
+        self._inflight -= 1
         return [int(v) for v in t.tolist()]
 
+    def _stop(self, kv: int) -> None:
+        """Rank 0: the stop message (header only: go = 0, the final verified length) and its answer."""
+        self.be.pipeline_pack(0, 1, 0, 1, kv)
+        self._rows_out(BUF_MSG, 0, self._S + 2, 1)
+        self._inflight += 1
+        self._result(None)                         # the late ranks answer every message; this one is discarded
+
     # ------------------------------------------------------------------ whole generation (collective)
+    def serve_forever(self) -> int:
+        """Ranks > 0 of a long-lived deployment (the CLI drivers under torchrun): take part in one generation after the
+        other until rank 0 calls `shutdown()`.  Returns the number of generations served.  (The reference's ranks > 0
+        simply `exit()`, generate.py:49-51: it has no multi-GPU decoding path.)"""
+        if self.rank == 0:
+            raise RuntimeError("serve_forever is for ranks > 0; rank 0 calls generate() and, at the end, shutdown()")
+        served = 0
+        while self.generate(None, [], 0, 0) is not None:
+            served += 1
+        return served
+
+    def shutdown(self) -> None:
+        """Rank 0: end the other ranks' `serve_forever` loops (collective: one broadcast)."""
+        if self.rank != 0:
+            raise RuntimeError("shutdown is called by rank 0")
+        if self.world > 1:
+            self._agree(None, [], 0, 0)
+
     def generate(self, prompt_ids: Optional[Sequence[int]], eos_token_ids: Sequence[int], max_steps: int,
-                 num_speculations: int) -> PipelineResult:
-        """Rank 0 passes the prompt and the settings; other ranks' arguments are ignored.  Mirrors SSG:32-99 (greedy)."""
-        be, E = self.be, self.E
-        P0, S, max_steps, eos = self._agree(prompt_ids, eos_token_ids, int(max_steps), int(num_speculations))
+                 num_speculations: int, on_step=None) -> Optional[PipelineResult]:
+        """Rank 0 passes the prompt and the settings; other ranks' arguments are ignored.  Mirrors SSG:32-99 (greedy).
+        on_step (rank 0): called after every speculation step with (draft tokens, number accepted, emitted tokens, next input
+        token); a truthy return value ends the generation after that step (stopping criteria, SSG:92-95; streamers hang here too).
+        Ranks > 0 get an empty result, or None when rank 0 shut the pipeline down instead of starting a generation."""
+        if self.rank == 0 and prompt_ids is None:
+            raise ValueError("rank 0 must pass the prompt")
+        agreed = self._agree(prompt_ids, eos_token_ids, int(max_steps), int(num_speculations))
+        if agreed is None:
+            return None
+        P0, S, max_steps, eos = agreed
         self._S = S
         if self.rank > 0:
             self._serve(P0, S)
             return PipelineResult([], None, [])
+        self._inflight = 0
+        self._kv_host = 0
+        try:
+            return self._drive(prompt_ids, eos, max_steps, S, on_step)
+        except BaseException:
+            # An error on rank 0 mid-generation (an inconsistent result block, a failed launch) must not leave the other ranks
+            # blocked in their next receive: collect the answers still in flight, send the stop message, then re-raise.  Best
+            # effort -- if the transport itself is what failed, the process group's timeout ends the others.
+            if self.world > 1:
+                try:
+                    while self._inflight > 0:
+                        self._result(None)
+                    self._stop(self._kv_host)
+                except Exception:       # noqa: BLE001
+                    pass
+            raise
+
+    def _drive(self, prompt_ids, eos, max_steps: int, S: int, on_step=None) -> PipelineResult:
+        """Rank 0's loop (SSG:51-95)."""
+        be, E = self.be, self.E
         out: List[int] = []
         steps: List[Tuple[int, int]] = []
         matches = gens = 0
@@ -292,6 +352,7 @@ class PipelineSpeculativeDecoder:
             if emitted != drafts[:n] + [nxt] or td > len(drafts):
                 raise RuntimeError("pipeline result block inconsistent with the drafted tokens")
             kv += P + n
+            self._kv_host = kv
             be.set_kv_len(kv)
             if attempt and n == S and nxt == guess:
                 toks = be.row_tokens(S + 2, S + (1 if room_chain else 0))
@@ -305,14 +366,17 @@ class PipelineSpeculativeDecoder:
             self._stats["draft_s"] += t1 - t0
             self._stats["verify_roundtrip_s"] += t2 - t1
             out.extend(emitted)
+            # the callback sees every step, the one an EOS then cuts included (the reference feeds its streamer inside the step,
+            # SSG:207-216, before the EOS check of SSG:82-91); its stop request ranks behind the EOS cut (SSG:92-95)
+            stop = bool(on_step(drafts[:td], n, emitted, nxt)) if on_step is not None else False
             hit = [out.index(e) for e in eos if e in out]
             if hit:
                 out = out[: hit[0]]
                 break
+            if stop:
+                break
             cur = [nxt]
         if self.world > 1:
-            be.pipeline_pack(0, 1, 0, 1, kv)            # stop message: header only (the final verified length)
-            self._rows_out(BUF_MSG, 0, S + 2, 1)
-            self._result(None)                         # the late ranks answer every message; this one is discarded
+            self._stop(kv)
         rate = (matches / gens) if gens else None
         return PipelineResult(out, rate, steps)

@@ -34,8 +34,11 @@ def pytest_collection_modifyitems(config, items):
         items[i] = it
 
 
+BIG_GOLDEN = ("full7b_rand_512",)     # multi-GB random-weight fixtures (oracle/make_golden.py BIG_CASES): tests/test_gpu_rand7b_parity.py
+
+
 def golden_names():
-    return sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json"))
+    return sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json") and f[:-5] not in BIG_GOLDEN)
 
 
 def load_golden(name):
@@ -95,3 +98,23 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+def make_wordlevel_tokenizer(vocab_size, path=None):
+    """A REAL `PreTrainedTokenizerFast` built offline (no checkpoint or tokenizer can be downloaded here): WordLevel over
+    `w<i>` words, whitespace pre-tokenizer, `<s>` prepended by a template post-processor like Llama's.  Ids: <unk> 0, <s> 1,
+    </s> 2, `abcdef` 3, `w<i>` -> i.  Saved to `path` (AutoTokenizer.from_pretrained reads it back) when given."""
+    import transformers
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    # id 3 is the word "abcdef": transformers' StopStringCriteria measures every token's string against that probe word and needs
+    # the tokenizer to be able to spell it (generation/stopping_criteria.py, clean_tokenizer_vocab)
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2, "abcdef": 3}
+    for i in range(4, vocab_size):
+        vocab[f"w{i}"] = i
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A", special_tokens=[("<s>", 1)])
+    fast = transformers.PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", unk_token="<unk>")
+    if path is not None:
+        fast.save_pretrained(path)
+    return fast

@@ -62,9 +62,7 @@ def test_correctness_driver_on_the_engine(gpu_device, monkeypatch, capsys, tmp_p
     _load_driver("benchmark", monkeypatch)
     correctness = _load_driver("correctness", monkeypatch)
     monkeypatch.setattr(sys, "argv", ["correctness.py"] + COMMON + ["--num_samples", "4", "--output_dir", str(tmp_path)])
-    with pytest.raises(SystemExit) as exc:
-        correctness.main()
-    assert exc.value.code == 0
+    assert correctness.main() == 0          # the exit code (the script passes it to sys.exit)
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert out == {"errors": 0, "error_pct": 0.0, "num_samples": 4}              # correctness.py:82-88
     dumped = glob.glob(str(tmp_path / "correctness_*.json"))
