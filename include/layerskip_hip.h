@@ -228,7 +228,16 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
 #define LSK_OPT_GRAPH_STEPS 7     /* 1: lsk_spec_generate replays its steady-state steps from hipGraphs (cached per speculation count
                                      and KV page count) on a stream of the engine's own; identical tokens; default 0 -- the host is not
                                      the limiter */
+#define LSK_OPT_CHAIN 8           /* 1: one-row passes run o_proj -> gate/up -> down as ONE resident grid with a continuous weight stream
+                                   * (csrc/lsk_chain.h; bit-identical rows; needs the whole GPU: every workgroup resident at once).  Default 0:
+                                   * measured at parity with the three launches -- the two all-to-all edges cost what the boundaries cost
+                                   * (profiles/r04_chain_persistent_layer.md) */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
+/* Device-side error count since the last call (synchronises `stream`; clears): non-zero when a workgroup of the resident one-row
+ * grid (LSK_OPT_CHAIN) gave up waiting for its peers -- the grid could not become co-resident (another process holds CUs of this
+ * GPU) -- in which case the rows it produced are unusable: the host wrapper raises and tells the caller to set LSK_OPT_CHAIN 0.
+ * (The reference has no such mode: torch launches never depend on co-residency.) */
+int lsk_engine_device_errors(lsk_engine* e, int32_t* count, void* stream);
 /* ---- sampling on the device (sample=True; GenerationConfig temperature / top_k / top_p, generator_base.py:35-44) ----
  * Both kernels are checked draw for draw against the oracle's model of them, and lsk_spec_step_sampled end to end against the
  * host-sampling path and the unmodified reference in distribution, on the GPU (tests/test_gpu_zz_sampling.py).  Parity with

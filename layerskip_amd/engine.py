@@ -119,6 +119,10 @@ class HipEngine:
             self._pack_weights(model)
             self._allocate(max_ctx, max_prompt)
         self._fingerprint = self._weights_fingerprint(model)
+        if os.environ.get("LSK_CHAIN") == "1":
+            # the resident one-row grid (csrc/lsk_chain.h): opt-in -- it needs every CU of the GPU at once, and it measured at parity
+            # with the three launches it replaces (profiles/r04_chain_persistent_layer.md)
+            self.set_option(_lib.LSK_OPT_CHAIN, 1)
 
     @property
     def model(self):
@@ -310,6 +314,16 @@ class HipEngine:
         except Exception:
             pass
 
+    def _check_device(self) -> None:
+        """Raise if a kernel reported a device-side failure since the last check (one 4-byte read; the callers have just
+        synchronised anyway).  Today: the resident one-row grid (LSK_OPT_CHAIN) could not become co-resident."""
+        n = ctypes.c_int32(0)
+        self._ck(self.lib.lsk_engine_device_errors(self._handle, ctypes.byref(n), self._stream))
+        if n.value:
+            raise _lib.LskError(f"{n.value} workgroups of the resident one-row grid gave up waiting for their peers: the GPU is shared "
+                                f"with another process (the grid needs every CU).  Decode with engine.set_option(LSK_OPT_CHAIN, 0) "
+                                f"(three launches per layer instead), or give the engine the GPU to itself; the tokens of this call are invalid")
+
     # ------------------------------------------------------------------ state
     def reset(self) -> None:
         self._ck(self.lib.lsk_engine_reset(self._handle, self._stream))
@@ -336,6 +350,7 @@ class HipEngine:
         res = LskStepResult()
         self._ck(self.lib.lsk_spec_step(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer),
                                      eos_arr, len(eos), ctypes.byref(res), self._stream))
+        self._check_device()
         n, s = res.num_matches, int(num_speculations)
         return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
                           list(res.draft_tokens[:s]), list(res.verified_tokens[: s + 1]))
@@ -352,6 +367,7 @@ class HipEngine:
         self._ck(self.lib.lsk_spec_generate(self._handle, ids, len(prompt_ids), int(num_speculations), int(exit_layer), eos_arr,
                                          len(eos), int(max_steps), out, ctypes.byref(n_out), ctypes.byref(tm), ctypes.byref(td),
                                          sd, sm, ctypes.byref(ns), self._stream))
+        self._check_device()
         steps = [(sd[i], sm[i]) for i in range(ns.value)]
         return list(out[: n_out.value]), tm.value, td.value, steps
 
@@ -391,6 +407,7 @@ class HipEngine:
                                              len(eos), float(temperature), int(top_k), float(top_p), int(seed) & (2 ** 64 - 1),
                                              int(offset) & (2 ** 64 - 1), scratch.data_ptr(), scratch.numel(), ctypes.byref(res),
                                              self._stream))
+        self._check_device()
         n, s = res.num_matches, int(num_speculations)
         return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
                           list(res.draft_tokens[:s]), list(res.verified_tokens[: s + 1]))
@@ -411,6 +428,7 @@ class HipEngine:
             float(temperature), int(top_k), float(top_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
             scratch.data_ptr(), scratch.numel(), out, ctypes.byref(n_out), ctypes.byref(tm), ctypes.byref(td), sd, sm,
             ctypes.byref(ns), self._stream))
+        self._check_device()
         steps = [(sd[i], sm[i]) for i in range(ns.value)]
         return list(out[: n_out.value]), tm.value, td.value, steps
 
@@ -423,6 +441,7 @@ class HipEngine:
         n_out = ctypes.c_int32(0)
         self._ck(self.lib.lsk_ar_generate(self._handle, ids, len(input_ids), int(layer_end or self.num_layers), eos_arr,
                                        len(eos), int(max_steps), out, ctypes.byref(n_out), self._stream))
+        self._check_device()
         return list(out[: n_out.value])
 
     def ar_step(self, input_ids: Sequence[int], layer_end: Optional[int] = None) -> int:
@@ -430,6 +449,7 @@ class HipEngine:
         tok = ctypes.c_int32(0)
         self._ck(self.lib.lsk_ar_step(self._handle, ids, len(input_ids), int(layer_end or self.num_layers),
                                    ctypes.byref(tok), self._stream))
+        self._check_device()
         return tok.value
 
     # ------------------------------------------------------------------ layer-range pipeline (rank-0 half of a step)
@@ -548,11 +568,11 @@ class HipEngine:
         self._ck(self.lib.lsk_engine_get_host_stats(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
         return {"enqueue_s": a.value, "wall_s": b.value, "steps": n.value}
 
-    PROFILE_CLASSES = ("qkv", "attention", "o_proj", "gate_up", "down", "lm_head")
+    PROFILE_CLASSES = ("qkv", "attention", "o_proj", "gate_up", "down", "lm_head", "chain")   # chain: o_proj + gate/up + down of a one-row pass, one launch
 
     def get_profile_table(self):
         """[{kernel, rows ("1" | ">1"), launches, ms, bytes}] for every decode-path kernel class since set_profile(True)."""
-        n = 12
+        n = 2 * len(self.PROFILE_CLASSES)
         ms, cnt, by = (ctypes.c_float * n)(), (ctypes.c_int32 * n)(), (ctypes.c_double * n)()
         self._ck(self.lib.lsk_engine_get_profile_table(self._handle, n, ms, cnt, by))
         out = []

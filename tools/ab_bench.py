@@ -128,7 +128,9 @@ def main():
                         "rounds": [round(x, 1) for x in tps[n]], **info[n], **prefill[n], "kernels_us": kern})
     for res in results:
         print(json.dumps(res), flush=True)
-    keys = list(results[0]["kernels_us"].keys())
+    keys = []
+    for res in results:
+        keys += [k for k in res["kernels_us"] if k not in keys]
     print(f"{'variant':24s} {'tok/s':>8s} {'best':>8s} {'acc':>6s} {'crc':>10s} {'prefill':>8s} " + " ".join(f"{k:>9s}" for k in keys))
     for res in results:
         print(f"{res['variant']:24s} {res['tok_s_median']:8.1f} {res['tok_s_best']:8.1f} {res['acceptance']:6.3f} {res['crc']:10d} {res['prefill_ms']:8.3f} "

@@ -30,6 +30,7 @@ WORDS, MAX_WGS = 12, 2048
 TICK_US = 0.01
 GEMM_NAMES = {(0, 1): "o_proj/down", (1, 2): "gate_up", (1, 3): "qkv", (1, 4): "lm_head", (0, 0): "plain_f32", (1, 0): "rms_f32"}
 GEMM_POINTS = ["ring_req", "rows_staged", "w_first", "w_unit0", "reduced", "stores_issued", "stores_acked"]
+CHAIN_POINTS = ["ring_req", "attn_row_staged", "o_reduced", "at_edge1", "edge1_passed", "norm_staged", "gu_reduced", "edge2_passed", "down_reduced"]
 ATTN_POINTS = ["loads_req", "qk_arrived", "pv_in_lds", "part_issued", "part_drained", "ticket", "out_issued", "out_acked"]
 
 
@@ -85,7 +86,30 @@ def main():
         rec = {"gap": None if prev_end is None else (start - prev_end) * TICK_US, "start_spread": (int(t0.max()) - start) * TICK_US,
                "span": (end - start) * TICK_US, "grid": grid, "cus": int(len(counts)), "max_wg_per_cu": int(counts.max()),
                "xcds": int(len(np.unique(d[:, 11] & 0xF)))}
-        if kind == 0:
+        if kind == 2:
+            # the resident one-row grid (lsk_chain.h): compute wave 0's stamps, and service wave 0's in the rows behind them
+            name = "chain"
+            rel = (d[:, 1:10] - start) * TICK_US
+            for k, pn in enumerate(CHAIN_POINTS):
+                col = rel[:, k][d[:, 1 + k] != 0]
+                if col.size:
+                    rec[pn] = float(np.median(col))
+                    rec[pn + "_max"] = float(col.max())
+                    rec[pn + "_min"] = float(col.min())
+            sv = data[i, g:2 * g]
+            ok = sv[:, 0] != 0
+            if ok.any():
+                rec["sv_gather1_begin"] = float(np.median((sv[ok, 0] - start) * TICK_US))
+                rec["sv_gather1_end"] = float(np.median((sv[ok, 1] - start) * TICK_US))
+                rec["sv_gather1_end_max"] = float(((sv[ok, 1] - start) * TICK_US).max())
+                rec["sv_sweeps1"] = float(np.mean(sv[ok, 2]))
+                rec["sv_gather2_begin"] = float(np.median((sv[ok, 3] - start) * TICK_US))
+                rec["sv_gather2_end"] = float(np.median((sv[ok, 4] - start) * TICK_US))
+                rec["sv_gather2_end_max"] = float(((sv[ok, 4] - start) * TICK_US).max())
+                rec["sv_sweeps2"] = float(np.mean(sv[ok, 5]))
+            end = int(max(d[:, 1:10].max(), t0.max()))
+            rec["span"] = (end - start) * TICK_US
+        elif kind == 0:
             name = GEMM_NAMES.get(((sub >> 4) & 15, sub & 15), str(sub & 255))
             if name == "o_proj/down":
                 name = "o_proj" if (sub >> 8) == cfg.hidden_size else "down"
