@@ -196,8 +196,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         else:
             step = engine.spec_step(new_ids, spec, exit_layer, eos_token_ids)
         n = step.num_matches
-        output_ids = list(output_ids)
-        output_ids.extend(step.emitted)
+        output_ids.extend(step.emitted)              # the CALLER's list grows in place, as in the reference (SSG:204-205), and is returned
         next_input = torch.tensor([[step.next_token]], dtype=input_ids.dtype, device=input_ids.device)
         if streamer:
             drafts = torch.tensor([step.draft_tokens[: step.num_drafts]])

@@ -136,17 +136,22 @@ def device_uniforms(n: int, tag: int, seed: int, offset: int) -> np.ndarray:
     return u01(np.stack(words, axis=1).reshape(-1)[:n])
 
 
-def key16(x: np.ndarray) -> np.ndarray:
+def key16(x: np.ndarray, dtype: str = "bf16") -> np.ndarray:
+    """Ordered 16-bit key of a logit (lsk_key16): exact at the model dtype's resolution.  bf16: the sign-folded upper half of the
+    fp32 pattern; fp16 (the -DLSK_ELEM_F16 library): the sign-folded fp16 pattern itself."""
+    if dtype == "fp16":
+        k = x.astype(np.float16).view(np.uint16).astype(np.int64)
+        return np.where(k & 0x8000, (~k) & 0xFFFF, k | 0x8000)
     b = x.astype(np.float32).view(np.uint32)
     k = (b >> np.uint32(16)).astype(np.int64)
     return np.where(b & np.uint32(0x80000000), (~k) & 0xFFFF, k | 0x8000)
 
 
-def device_warp(logits: np.ndarray, temperature: float, top_k: int, top_p: float):
+def device_warp(logits: np.ndarray, temperature: float, top_k: int, top_p: float, dtype: str = "bf16"):
     """(kept mask, probabilities) exactly as lsk_sample_kernel computes them (thresholds in the 16-bit key space)."""
     x = logits.astype(np.float32)
     v = x.shape[0]
-    keys = key16(x)
+    keys = key16(x, dtype)
     m = x.max()
     e = np.exp(((x - m) * np.float32(1.0 / temperature)).astype(np.float32)).astype(np.float32)
     K = 0

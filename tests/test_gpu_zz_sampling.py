@@ -93,6 +93,52 @@ def test_sample_rows_of_a_128k_vocabulary_match_the_model(gpu_device, temperatur
     eng.close()
 
 
+@pytest.mark.parametrize("temperature,top_k,top_p", [(0.7, 5, 1.0), (1.0, 0, 0.6), (0.9, 12, 0.8)])
+def test_fp16_library_filters_at_fp16_resolution(gpu_device, temperature, top_k, top_p):
+    """The -DLSK_ELEM_F16 library: logits are fp16 values, whose 10-bit mantissa the bf16-shaped key (upper half of the fp32 pattern)
+    would fold 8 : 1 -- top-k / top-p thresholds would then act on coarser buckets than the reference's warpers.
+    The key is the fp16 pattern itself: rows whose leading logits differ ONLY below bf16 resolution must be cut exactly where
+    HF's warpers cut them (all values distinct, so tie handling does not enter)."""
+    import transformers
+    from layerskip_amd import synthetic
+    from layerskip_amd.engine import HipEngine
+    from oracle import sampling_oracle as so
+    cfg = synthetic.make_config("tiny-mha")
+    model = synthetic.build_model(cfg, seed=0, exit_layer=2, late_damping=0.1, dtype=torch.float16).to(gpu_device)
+    eng = HipEngine(model, max_ctx=256, max_prompt=32)
+    assert eng.dtype == torch.float16
+    V = cfg.vocab_size
+    g = torch.Generator().manual_seed(5)
+    rows = (torch.randn(2, V, generator=g) * 1.5).to(torch.float16)
+    # the 24 leading logits of row 0: consecutive fp16 values around 6.0 (spacing 2^-8 * 4 = 0.0039..): eight of them share every
+    # bf16-resolution bucket
+    base = torch.tensor(6.0, dtype=torch.float16).view(torch.int16).item()
+    lead = torch.arange(base, base + 24, dtype=torch.int16).view(torch.float16)
+    perm = torch.randperm(V, generator=g)[:24]
+    rows[0, perm] = lead
+    assert rows[0].unique().numel() >= V - 40
+    rows_np = rows.float().numpy()
+    logits = rows.float().to(gpu_device).contiguous()
+    toks, probs = eng.sample_rows(logits, temperature, top_k, top_p, seed=7, offset=0, tag0=1)
+    probs = probs.cpu().numpy()
+    for r in range(2):
+        keep, want = so.device_warp(rows_np[r], temperature, top_k, top_p, dtype="fp16")
+        assert ((probs[r] > 0) == keep).all(), (r, int((probs[r] > 0).sum()), int(keep.sum()))
+        assert np.allclose(probs[r], want, rtol=0, atol=2e-6)
+        # and the kept set is HF's: the reference's own warpers on the same fp16-valued logits (llama_model_utils.py:75-107)
+        x = torch.tensor(rows_np[r:r + 1]) / temperature
+        if top_k > 0:
+            x = transformers.TopKLogitsWarper(top_k=top_k, filter_value=-float("inf"), min_tokens_to_keep=1)(None, x)
+        if 0 <= top_p <= 1.0:
+            x = transformers.TopPLogitsWarper(top_p=top_p, filter_value=-float("inf"), min_tokens_to_keep=1)(None, x)
+        hf_keep = torch.isfinite(x[0]).numpy()
+        diff = int((hf_keep != keep).sum())
+        assert diff <= 1, f"row {r}: kept set differs from HF's warpers in {diff} tokens"      # (<= 1: fp32 vs fp64 mass at the top-p boundary)
+        if top_k > 0 and top_p >= 1.0:
+            assert int(keep.sum()) == top_k                    # distinct values: exactly k survive -- a bf16-shaped key would keep up to 8x
+    eng.close()
+
+
 def test_accept_sampled_kernel_matches_the_model(gpu_device):
     import lsk_test_lib
     from oracle import sampling_oracle as so

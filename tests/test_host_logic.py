@@ -189,3 +189,19 @@ def test_engine_status_checks_use_the_engines_own_library():
         eng.set_option(3, 1)
     with pytest.raises(LskError, match="stub says no"):
         _ = eng.kv_len
+
+
+def test_single_step_extends_the_callers_output_list_in_place(fake):
+    """The reference's step extends the list it was handed and returns that same object (self_speculation_generator.py:204-205,
+    :223-229): a caller holding the list sees the new tokens without reading the return value."""
+    import torch
+    rec = load_golden("tiny_mha_s0")
+    model = build_case_model(rec)
+    strat = hip_strategies.HipSelfSpeculativeGenerationStrategy()
+    mine = [7, 7]                      # (whatever the caller already collected stays in front)
+    ids = rec["prompt"]
+    nxt, out, past, n, td = strat.single_step_speculation(
+        model=model, input_ids_list=ids, input_ids=torch.tensor([ids]), output_ids=mine, num_speculations=3, past_key_values=None,
+        exit_layer=rec["exit_layer"], eos_token_ids=rec["eos_token_ids"], calls=0, sample=False)
+    assert out is mine and len(mine) == 2 + n + 1 and mine[:2] == [7, 7]
+    assert mine[2:] == rec["fp32"]["spec_tokens"][: n + 1]
