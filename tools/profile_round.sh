@@ -8,10 +8,10 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-gpu-reference --no-sampled --no-operating-points"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-gpu-reference --no-sampled --no-operating-points --no-reference-parity --no-other-configs"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o stats -- $BENCH --steps 2 --warmup 1 > "$OUT/stats_bench.log" 2>&1
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_7B_spec.csv"
-SHORT="$BENCH --steps 1 --warmup 0 --max-steps 48"
+SHORT="$BENCH --weights gpu --steps 1 --warmup 0 --max-steps 48"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
   tag=$(echo $pass | cut -d' ' -f1)
   rm -rf /tmp/prof_pmc
