@@ -60,6 +60,13 @@ CASES = {
 BIG_CASES = {
     "full7b_rand_512": synthetic.SyntheticCase("llama2-7B", seed=0, prompt_len=512, prompt_seed=0, max_steps=192,
                                                late_damping=0.03),
+    # the other single-GPU BASELINE configs on bench.py's `other_configs` recipe (random init, late damping 0.03; CPU generator here):
+    # llama3-8B (config #3: GQA 32:8, 128 256-entry vocabulary, theta 5e5) and llama3.2-1B (config #1's shape: d = 64, tied embeddings,
+    # llama3 RoPE scaling)
+    "full8b_rand_512": synthetic.SyntheticCase("llama3-8B", seed=0, prompt_len=512, prompt_seed=0, max_steps=128,
+                                               late_damping=0.03),
+    "full1b_rand_512": synthetic.SyntheticCase("llama3.2-1B", seed=0, prompt_len=512, prompt_seed=0, max_steps=192,
+                                               late_damping=0.03),
 }
 # EOS cases are derived: the eos id is the first token at index >= k of the base case's fp32 output that has not occurred before.
 EOS_CASES = {"tiny_mha_s0_eos": ("tiny_mha_s0", 3), "tiny_gqa_s0_eos": ("tiny_gqa_s0", 5), "tiny_mha_s1_eos": ("tiny_mha_s1", 10)}
@@ -268,7 +275,7 @@ def main():
             continue
         records[name] = build_case(ref, name, case)
     for name, case in BIG_CASES.items():
-        if args.only and args.only in name:
+        if args.only and args.only == name:
             records[name] = build_big_case(ref, name, case)
     for name, (base, k) in EOS_CASES.items():
         if args.only and args.only not in name:

@@ -34,7 +34,7 @@ def pytest_collection_modifyitems(config, items):
         items[i] = it
 
 
-BIG_GOLDEN = ("full7b_rand_512",)     # multi-GB random-weight fixtures (oracle/make_golden.py BIG_CASES): tests/test_gpu_rand7b_parity.py
+BIG_GOLDEN = ("full7b_rand_512", "full8b_rand_512", "full1b_rand_512")     # multi-GB random-weight fixtures (oracle/make_golden.py BIG_CASES): tests/test_gpu_rand7b_parity.py
 
 
 def golden_names():

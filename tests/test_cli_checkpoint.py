@@ -271,3 +271,20 @@ def test_correctness_main_under_a_torchrun_style_launch(ckpt, tmp_path):
     assert code == 0                                             # speculative == autoregressive on every sample (correctness.py:82-88)
     out = [json.load(open(os.path.join(tmp_path, f))) for f in os.listdir(tmp_path) if f.startswith("correctness_")]
     assert out == [{"errors": 0, "error_pct": 0.0, "num_samples": 2}]
+
+
+def test_tied_embeddings_checkpoint_loads_with_the_head_tied(tmp_path):
+    """llama3.2-1B's layout (config #1): `tie_word_embeddings` checkpoints store the embedding only; the loader ties the head to it."""
+    from layerskip_amd import synthetic
+    from layerskip_amd.checkpoint import load_layer_range
+    cfg = synthetic.make_config("tiny-d64")
+    assert cfg.tie_word_embeddings
+    model = synthetic.build_model(cfg, seed=2, exit_layer=2, late_damping=0.1)
+    path = str(tmp_path / "tied")
+    model.save_pretrained(path, safe_serialization=True)
+    part = load_layer_range(path, (1, 3), device="cpu")
+    assert part.lm_head.weight.data_ptr() == part.model.embed_tokens.weight.data_ptr()
+    assert torch.equal(part.lm_head.weight, model.model.embed_tokens.weight)
+    assert part.model.layers[0].mlp.up_proj.weight.device.type == "meta" and part.model.layers[2].mlp.up_proj.weight.device.type == "cpu"
+    # and the partial model decodes like the whole one through the CPU stage backend (rank-style: layers [1, 3) only hold weights)
+    assert torch.equal(part.model.layers[1].self_attn.q_proj.weight, model.model.layers[1].self_attn.q_proj.weight)

@@ -17,15 +17,16 @@ from its own fp32 logits.  So the gates are:
     engine's speculative and autoregressive outputs are bit-identical.
 """
 import math
+import os
 
 import pytest
 import torch
 
-from conftest import build_case_model, load_golden
+from conftest import GOLDEN_DIR, build_case_model, load_golden
 
 pytestmark = pytest.mark.gpu
 
-NAME = "full7b_rand_512"
+NAMES = [n for n in ("full1b_rand_512", "full7b_rand_512", "full8b_rand_512") if os.path.exists(os.path.join(GOLDEN_DIR, n + ".json"))]
 # a decision may differ from the reference's only where the reference's own margin is below this many bf16 ulp of its top logit:
 # two correct bf16 implementations each sit ~1.8 ulp rms from the fp32 logits (fixture: reference_bf16_vs_fp32), so their
 # DIFFERENCE has ~2.6 ulp rms and a top-2 order can flip at margins of a few ulp.  Measured worst case is printed by the tests.
@@ -33,12 +34,12 @@ TIE_ULP = 4.0
 RMS_FACTOR = 1.1          # engine rms error vs fp32 <= RMS_FACTOR x the reference-bf16 rms error vs fp32
 
 
-@pytest.fixture(scope="module")
-def case(gpu_device):
+@pytest.fixture(scope="module", params=NAMES)
+def case(request, gpu_device):
     free, _ = torch.cuda.mem_get_info()
-    if free < 40e9:
-        pytest.skip("needs ~30 GB of free HBM")
-    rec = load_golden(NAME)
+    if free < 48e9:
+        pytest.skip("needs ~40 GB of free HBM")
+    rec = load_golden(request.param)
     model = build_case_model(rec, gpu_device)       # CPU generator: the same bits as the fixture's checkpoint and as bench.py's
     yield rec, model
     del model
@@ -95,7 +96,7 @@ def test_logits_as_close_to_fp32_as_the_reference_bf16_run(case):
         got, _ = _teacher_forced(eng, seq, rows, layer_end)
         st = _err_stats(got, rows)
         e, r = st["engine"], st["reference_bf16"]
-        print(f"\n{NAME} {label}: vs the reference's fp32 logits over {e['entries']} entries -- engine rms {e['rms_ulp']:.3f} ulp "
+        print(f"\n{rec['name']} {label}: vs the reference's fp32 logits over {e['entries']} entries -- engine rms {e['rms_ulp']:.3f} ulp "
               f"(max {e['max_ulp']:.2f}), rel rms {e['rms_rel']:.2e} (max {e['max_rel']:.2e}); reference bf16 rms {r['rms_ulp']:.3f} ulp "
               f"(max {r['max_ulp']:.2f}), rel rms {r['rms_rel']:.2e} (max {r['max_rel']:.2e})")
         assert e["rms_ulp"] <= RMS_FACTOR * r["rms_ulp"], f"{label}: engine rms {e['rms_ulp']} ulp vs reference bf16 {r['rms_ulp']}"
@@ -112,7 +113,7 @@ def test_decisions_along_the_reference_trajectory(case):
     eng = get_engine(model)
     _, pred = _teacher_forced(eng, seq, [], eng.num_layers)
     flips = [(i, gold["spec_margins_ulp"][i]) for i, tok in enumerate(gold["spec_tokens"]) if pred[P - 1 + i] != tok]
-    print(f"\n{NAME}: teacher-forced argmax agreement {len(gold['spec_tokens']) - len(flips)}/{len(gold['spec_tokens'])}; reference margins (ulp) "
+    print(f"\n{rec['name']}: teacher-forced argmax agreement {len(gold['spec_tokens']) - len(flips)}/{len(gold['spec_tokens'])}; reference margins (ulp) "
           f"at the disagreements: {[round(m, 2) for _, m in flips]}; {sum(1 for m in gold['spec_margins_ulp'] if m < 1)} reference decisions "
           f"are below one ulp")
     for i, m in flips:
@@ -130,7 +131,7 @@ def test_decisions_along_the_reference_trajectory(case):
                 bad.append((pos + j, gold["draft_margins_ulp"][k + j]))
         k += td
         pos += n + 1
-    print(f"{NAME}: draft-head decisions on the trajectory that differ: {len(bad)}, reference margins there (ulp): {[round(m, 2) for _, m in bad]}")
+    print(f"{rec['name']}: draft-head decisions on the trajectory that differ: {len(bad)}, reference margins there (ulp): {[round(m, 2) for _, m in bad]}")
     for p_, m in bad:
         assert m < TIE_ULP, f"row {p_}: draft token differs at a healthy reference margin of {m:.2f} ulp"
 
@@ -149,7 +150,7 @@ def test_free_running_generation_up_to_the_first_near_tie(case):
     assert res.predicted_tokens == ar.predicted_tokens, "engine: speculative != autoregressive"
     assert len(res.predicted_tokens) == rec["max_steps"]
     first = next((i for i, (a, b) in enumerate(zip(res.predicted_tokens, gold["spec_tokens"])) if a != b), None)
-    print(f"\n{NAME}: free-running generation identical to the reference's bf16 run for the first "
+    print(f"\n{rec['name']}: free-running generation identical to the reference's bf16 run for the first "
           f"{len(gold['spec_tokens']) if first is None else first} of {len(gold['spec_tokens'])} tokens"
           + ("" if first is None else f"; the reference's margin at the first difference: {gold['spec_margins_ulp'][first]:.2f} ulp")
           + f"; acceptance {res.acceptance_rate:.4f} (reference {gold['acceptance_rate']:.4f})")
