@@ -225,6 +225,73 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
     float ss[MB];
     float sv[MB];                 // per-row 1/rms (PRO_RMS), wave-uniform
     u32x4 ring[LSK_SPW];
+    // Multi-row RMSNorm launches of a one-chunk K (the verify pass's q/k/v, gate/up and lm_head at hidden <= 4096): the normalisation
+    // of 8 rows is ~450 VALU instructions per thread, ~2 us for the CU whoever executes them, and it used to start only when the LAST
+    // wave was through the throttled issue of its ring (4.4 us: requests leave a CU at the HBM rate) -- a hole in the stream, rows staged
+    // at 6.7 us against 4.2 us for one row (profiles/r03_kernel_timeline.md section 2).  Here the first four waves (one per SIMD) take the
+    // WHOLE prologue -- their own 8-element slices and those of the four late waves: rows, squares, statistics, normalisation, staging --
+    // while the late waves do nothing but request their ring, and only once the early waves' requests are in the queue (behind the
+    // statistics barrier: the CU's address path is busy with the early waves' 64 KiB until then).  Every partial sum is the one the
+    // old form computed (slice s = tid + 256 summed in the same order by the thread that now owns it, reduced over the same 64 lanes,
+    // stored in the late wave's slot of `red`): bit-identical statistics, rows and products.
+    constexpr bool kSplitPrologue = (PRO == PRO_RMS) && (MB > 1) && (MB <= 8) && (EPI != EPI_HEAD);   // (the one multi-row lm_head launch of a step measured 1.4 us slower with it)
+    const bool split = kSplitPrologue && nchunks == 1;
+    elem8 xr2[MB];                    // (dead in the templates without the split form)
+    elem8 nw2 = {};
+    if (kSplitPrologue && split) {
+        float ss2[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) { ss[i] = 0.f; ss2[i] = 0.f; }
+        if (w < LSK_WAVES / 2) {
+            // unconditional loads from clamped (always valid) slices: behind a lane predicate hipcc closes the region with a register
+            // copy of a loaded value, i.e. a wait for the rows IN FRONT of the ring (ISA: s_waitcnt vmcnt(2); v_mov)
+            {
+                const int k0 = min(tid * 8, cur.steps_c * 32 - 8);
+                const int k1 = min((tid + LSK_THREADS / 2) * 8, cur.steps_c * 32 - 8);
+                nw = *(const elem8*)(hp.norm_w + k0);
+                nw2 = *(const elem8*)(hp.norm_w + k1);
+#pragma unroll
+                for (int i = 0; i < MB; ++i) xr[i] = *(const elem8*)(hp.x + (size_t)min(i, M - 1) * hp.ldx + k0);
+#pragma unroll
+                for (int i = 0; i < MB; ++i) xr2[i] = *(const elem8*)(hp.x + (size_t)min(i, M - 1) * hp.ldx + k1);
+            }
+#pragma unroll
+            for (int s = 0; s < LSK_SPW; ++s) {
+                const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
+                ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
+            }
+            lsk_accumulate_squares<MB>(xr, tid * 8 < cur.steps_c * 32, ss);
+            lsk_accumulate_squares<MB>(xr2, (tid + LSK_THREADS / 2) * 8 < cur.steps_c * 32, ss2);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const float t = wave_sum(ss[i]);
+                const float t2 = wave_sum(ss2[i]);
+                if (lane == 0 && i < M) { red[i * LSK_WAVES + w] = t; red[i * LSK_WAVES + w + LSK_WAVES / 2] = t2; }
+            }
+        }
+        __syncthreads();
+        if (w < LSK_WAVES / 2) {
+            float my_inv = 0.f;
+            if (lane < MB) {
+                float t = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < LSK_WAVES; ++ww) t += red[lane * LSK_WAVES + ww];
+                my_inv = 1.0f / sqrtf(t / (float)hp.K + hp.eps);
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                sv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_inv), i));
+            lsk_store_chunk<PRO, MB>(hp, xs, xstride, sv, cur.steps_c, tid, xr, nw);
+            lsk_store_chunk<PRO, MB>(hp, xs, xstride, sv, cur.steps_c, tid + LSK_THREADS / 2, xr2, nw2);
+        } else {
+#pragma unroll
+            for (int s = 0; s < LSK_SPW; ++s) {
+                const unsigned off = (s < cur.nvalid) ? cur.off0 + (unsigned)s * 1024u : LSK_OOB_OFFSET;
+                ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
+            }
+        }
+        LSK_TRACE_POINT(1);
+    } else {
     if (PRO == PRO_RMS) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) ss[i] = 0.f;
@@ -273,6 +340,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
 #ifdef LSK_TRACE
     if (PRO == PRO_PLAIN) LSK_TRACE_POINT(8);                     // wave 0's slice of the rows arrived and went to LDS
 #endif
+    }   // (the one-launch prologue; the split form above has staged its rows already)
     __syncthreads();
     LSK_TRACE_POINT(2);                                           // rows arrived, normalised, staged
     // prefetch of chunk 1's rows: BEHIND the barrier -- in front of it the requests waited in the CU's address queue behind the eight
