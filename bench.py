@@ -61,7 +61,7 @@ def parse_args():
     ap.add_argument("--no-gpu-reference", action="store_true",
                     help="skip the leg that times the reference algorithm on THIS GPU (torch-ROCm eager ops)")
     ap.add_argument("--gpu-reference", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling: now the default
-    ap.add_argument("--gpu-reference-tokens", type=int, default=128)
+    ap.add_argument("--gpu-reference-tokens", type=int, default=256)
     ap.add_argument("--no-sampled", action="store_true", help="skip the sample=True throughput leg")
     ap.add_argument("--no-operating-points", action="store_true",
                     help="skip the two extra operating points (late damping giving acceptance ~0.5 and ~0.8)")
