@@ -10,13 +10,15 @@
 //           (repeat_kv, modeling_llama.py:179-188, never materialises).  Walking ALL group x M rows of a KV head in one
 //           workgroup (two tiles at 8B) was measured and rejected: 8 x pages workgroups and a 28-row serial combine
 //           made the verify pass 17.8 us against 7.0 us for the draft pass (profiles/r02_attention_gqa.md).
-//           A wave issues ALL of its loads up front -- K as MFMA B-fragments straight from
-//           the page ([kv_head][slot][d] rows, 64 B per key per k-step), V as B-fragments from the TRANSPOSED
-//           page ([kv_head][d][slot]: 8 consecutive keys of one feature are 16 contiguous bytes), Q as A-fragments.
-//           S = QK^T lands in the MFMA C layout; causal masking is index arithmetic (a row at position base + r sees
+//           A wave issues ALL of its loads up front -- K as MFMA A-fragments straight from
+//           the page ([kv_head][slot][d] rows, 64 B per key per k-step), V as A-fragments from the TRANSPOSED
+//           page ([kv_head][d][slot]: 8 consecutive keys of one feature are 16 contiguous bytes), Q as B-fragments.
+//           Both products are computed TRANSPOSED (round 4): S^T = K Q^T lands in the MFMA C layout with a lane holding 8
+//           consecutive keys of ONE query row, which is the B-operand layout of O^T = V^T P^T -- P never leaves the registers.
+//           Causal masking is index arithmetic (a row at position base + r sees
 //           keys <= its position; this replaces the additive masks of llama_model_utils.py:21-59); fp32 softmax
-//           statistics per row via 16-lane DPP reductions; P is rounded to bf16 (as HF's eager path and torch's flash
-//           kernels both do before the second GEMM), transposed C->A layout through 1 KiB of LDS per wave, O = P V.
+//           statistics per row in-lane + two gfx950 row swaps; P is rounded to bf16 (as HF's eager path and torch's flash
+//           kernels both do before the second GEMM).
 //           The 4 waves are merged in a fixed order into ONE (max, sum, acc[d]) partial per (row, head, page).
 //   phase 2: the page partials of a (row, head) are merged in page order into the bf16 attention output
 //           -- by the LAST page-workgroup of the head column to arrive, inside the same launch (write-through
@@ -54,6 +56,7 @@ struct AttnSplitParams {
     int n_pages;            // page-workgroups per head column in this launch
     int heads_per_wg;       // HW: query heads (of one KV head) per workgroup, HW * M <= 16, HW divides group
     int inv_m;              // ceil(256 / M): i / M == (i * inv_m) >> 8 for every row index i < 16
+    int identity_table;     // block_table[i] == i for every page (the engine's default): the kernel skips the table read
     LSK_TRACE_FIELD
 };
 
@@ -67,13 +70,13 @@ struct AttnHot {
     const int* kv_len;
     int ldq;
     int geom;               // n_kv | group << 16
-    int rows;               // M | heads_per_wg << 8 | inv_m << 16
+    int rows;               // M | heads_per_wg << 8 | inv_m << 16 | identity block table << 30
     int pos_off;
 };
 
-#define LSK_ATTN_LDS_PBUF 0
-#define LSK_ATTN_LDS_SM 5120
-template <int HD> constexpr int lsk_attn_lds_bytes() { return 5120 + LSK_ATTN_WAVES * 16 * (HD + 2) * 4 + 16; }
+// LDS: the 4 waves' (acc[HD], max, sum) rows, row stride HD + 4 floats (16-byte aligned rows for the 16-byte O^T stores; 132 or 68
+// dwords = 4 modulo 64 banks: the 16 lanes of a store pass cover all 64 banks once), + the last-arriver flag
+template <int HD> constexpr int lsk_attn_lds_bytes() { return LSK_ATTN_WAVES * 16 * (HD + 4) * 4 + 16; }
 
 struct AttnCombineParams {
     const float* part;
@@ -85,17 +88,16 @@ struct AttnCombineParams {
     int ldo;
 };
 
-template <int HD>
+template <int HD, bool FUSED>
 __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplitParams& p, const int col, const int page_l, unsigned char* lds) {
     constexpr int KS = HD / 32;              // k-steps of QK^T
     constexpr int DT = HD / 16;              // output column tiles of PV
     constexpr int PSTRIDE = HD + 2;
-    constexpr int PB_STRIDE = 80;            // bytes per P row in LDS: 32 bf16 + 16 B pad
+    constexpr int LS = HD + 4;               // row stride of the LDS merge buffer (PSTRIDE is the stride of the partials in memory)
     LSK_TRACE_DECL;
     LSK_TRACE_POINT(0);
-    unsigned char* pbuf = lds + LSK_ATTN_LDS_PBUF;           // [4 waves][16][80 B]
-    float* sm = (float*)(lds + LSK_ATTN_LDS_SM);              // [4 waves][16][HD + 2]
-    int* s_last_p = (int*)(lds + LSK_ATTN_LDS_SM + LSK_ATTN_WAVES * 16 * PSTRIDE * 4);
+    float* sm = (float*)lds;                                  // [4 waves][16][HD + 4]
+    int* s_last_p = (int*)(lds + LSK_ATTN_WAVES * 16 * LS * 4);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,40 +106,50 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
     const int g = lane >> 4;
     const int M = hp.rows & 0xff;
     const int HW = (hp.rows >> 8) & 0xff;    // query heads of ONE KV head served by this workgroup: HW * M <= 16 rows
-    const int inv_m = hp.rows >> 16;         // ceil(256 / M): i / M == (i * inv_m) >> 8 for every row index i < 16
+    const int inv_m = (hp.rows >> 16) & 0x3fff;   // ceil(256 / M): i / M == (i * inv_m) >> 8 for every row index i < 16
+    const bool ident = (hp.rows >> 30) & 1;  // the block table is the identity (the engine's default): physical page = logical page
     const int n_kv = hp.geom & 0xffff;
     const int head0 = col * HW;              // first query head
     const int kvh = head0 / (hp.geom >> 16);
     const int n_rows = HW * M;               // MFMA row i = (head head0 + i / M, verify row i % M)
     const int key0 = page_l * LSK_ATTN_PAGE;
-    const bool fused = p.counters != nullptr;
+    constexpr bool fused = FUSED;            // p.counters != nullptr, as a compile-time fact: the single-kernel form has no early exit
     // ---- every load of this wave up front ----
     // the two device scalars first, in ONE scalar-load clause; their pointers (like every argument the address arithmetic below
     // needs) are preloaded kernel arguments, so this is the FIRST scalar round trip of the wave, not the second.  (Pinned: hipcc
     // otherwise sinks the block-table read below the early return; nothing with side effects may stand BEFORE the two reads:
     // hipcc then no longer proves them clobber-free and turns the scalar loads into vector loads.)
-    const int page = hp.block_table[page_l];
+    // With the identity table (a flag in the preloaded arguments) the page id needs NO memory at all: K and V are requested before
+    // any scalar read has returned -- the block-table read was a round trip in front of every request of this latency-bound
+    // kernel -- and the context length (masks only) arrives under their flight time.
+    int page = page_l;
     const int kv_now = *hp.kv_len;
-    asm volatile("" : : "s"(page), "s"(kv_now));
-    const int base_pos = kv_now + hp.pos_off;
+    if (!ident) {
+        page = hp.block_table[page_l];
+        asm volatile("" : : "s"(page), "s"(kv_now));
+    }
     const int qi = min(c16, n_rows - 1);
     const int qh = (qi * inv_m) >> 8;
     const elem_t* qp = hp.q + (size_t)(qi - qh * M) * hp.ldq + (size_t)(head0 + qh) * HD + g * 8;
     elem8 kb[2][KS], vb[DT], qa[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qa[ks] = *(const elem8*)(qp + ks * 32);
-    if (key0 > base_pos + M - 1 && !fused) return;     // page entirely in the future of every row
     const size_t head_base = ((size_t)page * n_kv + kvh) * LSK_ATTN_PAGE * HD;
-    const elem_t* kp = hp.kpool + head_base + (size_t)(w * 32 + c16) * HD + g * 8;
+    // K is the A operand of S^T = K Q^T: tile t's row a is key w*32 + (a/4)*8 + t*4 + a%4 (see below)
+    const elem_t* kp = hp.kpool + head_base + (size_t)(w * 32 + (c16 >> 2) * 8 + (c16 & 3)) * HD + g * 8;
     const elem_t* vp = hp.vpool + head_base + (size_t)c16 * LSK_ATTN_PAGE + w * 32 + g * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         kb[0][ks] = *(const elem8*)(kp + ks * 32);
-        kb[1][ks] = *(const elem8*)(kp + 16 * HD + ks * 32);
+        kb[1][ks] = *(const elem8*)(kp + 4 * HD + ks * 32);
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vb[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
     LSK_TRACE_POINT(1);                                           // every load requested
+    const int base_pos = kv_now + hp.pos_off;
+    // Two-kernel form only: a page entirely in the future of every row contributes nothing.  Tested AFTER the requests so that no request
+    // waits for the context length; the page is inside the pool either way, the reads of a skipped page are merely dropped.
+    if (!fused && key0 > base_pos + M - 1) return;
     // Slots beyond the last key any row can see were never written: the pool is caller-owned memory and may hold
     // anything there, NaN / Inf bit patterns included.  K is harmless (masked scores are SELECTED away, never
     // multiplied), V is not (P = 0 times NaN): zero those V elements.  Only the last page in reach has any.
@@ -153,56 +165,54 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
         }
     }
 
-    // ---- S = Q K^T (C layout: column = key, rows g*4 + r) ----
+    // ---- S^T = K Q^T (C layout: column = query row c16, rows g*4 + r = keys) ----
+    // The TRANSPOSED score tile: K is the A operand, its tile rows permuted in the addresses above so that this lane's 8 accumulator
+    // registers are 8 CONSECUTIVE keys (s0[r] = key kbase + r, s1[r] = key kbase + 4 + r) of ONE query row.  That is already the
+    // B-operand layout of O^T = V^T P^T (k = g*8 + j, n = c16): P never goes through LDS, a row's softmax statistics are 8 in-lane
+    // values and two row swaps instead of 4 x (4 + 4) DPP steps per register, and O^T leaves the MFMA with 4 adjacent features per
+    // lane (one 16-byte LDS store, only the lanes of real rows).  Round 3's form -- S in the C layout, P transposed through 1 KiB of
+    // LDS per wave -- spent 0.75 us between the arrival of K and the last P store and had SQ_LDS_BANK_CONFLICT at 0.38 of the LDS
+    // cycles (2-byte P stores, [16][HD + 2] fp32 rows); same products, the 32 keys of a wave summed in a different order.
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        s0 = LSK_MFMA_16x16x32(qa[ks], kb[0][ks], s0, 0, 0, 0);
-        s1 = LSK_MFMA_16x16x32(qa[ks], kb[1][ks], s1, 0, 0, 0);
+        s0 = LSK_MFMA_16x16x32(kb[0][ks], qa[ks], s0, 0, 0, 0);
+        s1 = LSK_MFMA_16x16x32(kb[1][ks], qa[ks], s1, 0, 0, 0);
     }
     LSK_TRACE_POINT(2);                                           // Q and K arrived, S issued
-    const int keyA = key0 + w * 32 + c16;    // key of s0's column; s1's is keyA + 16
-    float mrow[4], lrow[4];
-    unsigned char* pw = pbuf + w * 16 * PB_STRIDE;
+    const int kbase = key0 + w * 32 + g * 8;                      // first of this lane's 8 keys
+    const int ihq = (c16 * inv_m) >> 8;
+    const int lim = (c16 < n_rows) ? base_pos + (c16 - ihq * M) : -1;    // last visible key of this lane's row; a padding row sees none
+    float sc[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int i = g * 4 + r;
-        const int ih = (i * inv_m) >> 8;
-        const int lim = base_pos + (i - ih * M);     // last visible key of this row
-        const bool ok0 = (i < n_rows) && (keyA <= lim);
-        const bool ok1 = (i < n_rows) && (keyA + 16 <= lim);
-        const float a0 = ok0 ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
-        const float a1 = ok1 ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
-        float m = fmaxf(a0, a1);
-        m = row16_max(m);
-        const float p0 = ok0 ? __builtin_amdgcn_exp2f(a0 - m) : 0.f;
-        const float p1 = ok1 ? __builtin_amdgcn_exp2f(a1 - m) : 0.f;
-        float l = p0 + p1;
-        l = row16_sum(l);
-        mrow[r] = m;
-        lrow[r] = l;
-        *(elem_t*)(pw + i * PB_STRIDE + c16 * 2) = f2e(p0);
-        *(elem_t*)(pw + i * PB_STRIDE + (16 + c16) * 2) = f2e(p1);
+        sc[r] = (kbase + r <= lim) ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
+        sc[4 + r] = (kbase + 4 + r <= lim) ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // ---- O = P V : A fragment = P[row c16][keys g*8 .. g*8+7] ----
-    const elem8 pa = *(const elem8*)(pw + c16 * PB_STRIDE + g * 16);
-    float* dst = sm + (size_t)w * 16 * PSTRIDE;
+    const float mrow = col4_max(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))));
+    float pe[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pe[j] = (kbase + j <= lim) ? __builtin_amdgcn_exp2f(sc[j] - mrow) : 0.f;
+    const float lrow = col4_sum(((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7])));
+    // P is rounded to bf16 (as HF's eager path and torch's flash kernels both do before the second GEMM)
+    elem8 pa;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pa[j] = f2e(pe[j]);
+    // ---- O^T = V^T P^T : rows = features dt*16 + g*4 + r, column = query row c16 ----
+    float* dst = sm + (size_t)(w * 16 + c16) * LS;
+    f32x4 o[DT];                                                  // DT independent accumulators: the MFMAs issue back to back
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        o = LSK_MFMA_16x16x32(pa, vb[dt], o, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(g * 4 + r) * PSTRIDE + dt * 16 + c16] = o[r];
+        o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        o[dt] = LSK_MFMA_16x16x32(vb[dt], pa, o[dt], 0, 0, 0);
     }
-    if (c16 == 0) {
+    if (c16 < n_rows) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dst[(g * 4 + r) * PSTRIDE + HD] = mrow[r];
-            dst[(g * 4 + r) * PSTRIDE + HD + 1] = lrow[r];
-        }
+        for (int dt = 0; dt < DT; ++dt) *(f32x4*)(dst + dt * 16 + g * 4) = o[dt];
+    }
+    if (g == 0 && c16 < n_rows) {
+        dst[HD] = mrow;
+        dst[HD + 1] = lrow;
     }
     __syncthreads();
     LSK_TRACE_POINT(3);                                           // O = P V of the 4 waves in LDS
@@ -217,7 +227,7 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
             const int d = e - i * PSTRIDE;
             float m = LSK_ATTN_NEG;
 #pragma unroll
-            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + i) * PSTRIDE + HD]);
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + i) * LS + HD]);
             float v;
             if (d == HD) {
                 v = m;
@@ -225,7 +235,7 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
                 v = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
-                    const float* src = sm + (ww * 16 + i) * PSTRIDE;
+                    const float* src = sm + (ww * 16 + i) * LS;
                     v += src[d] * __builtin_amdgcn_exp2f(src[HD] - m);      // d == HD + 1: the running sum l
                 }
             }
@@ -242,7 +252,7 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
             float f[LSK_ATTN_WAVES];
             float m = LSK_ATTN_NEG;
 #pragma unroll
-            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) { f[ww] = sm[(ww * 16 + i) * PSTRIDE + HD]; m = fmaxf(m, f[ww]); }
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) { f[ww] = sm[(ww * 16 + i) * LS + HD]; m = fmaxf(m, f[ww]); }
 #pragma unroll
             for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) f[ww] = __builtin_amdgcn_exp2f(f[ww] - m);
             const int ih = (i * inv_m) >> 8;
@@ -252,14 +262,13 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
             if (q < HD / 4) {
 #pragma unroll
                 for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
-                    const float2 a = *(const float2*)(sm + (ww * 16 + i) * PSTRIDE + d);        // 8-byte aligned: PSTRIDE and d are even
-                    const float2 b = *(const float2*)(sm + (ww * 16 + i) * PSTRIDE + d + 2);
-                    v[0] += a.x * f[ww]; v[1] += a.y * f[ww]; v[2] += b.x * f[ww]; v[3] += b.y * f[ww];
+                    const f32x4 a = *(const f32x4*)(sm + (ww * 16 + i) * LS + d);        // 16-byte aligned: LS and d are multiples of 4
+                    v[0] += a[0] * f[ww]; v[1] += a[1] * f[ww]; v[2] += a[2] * f[ww]; v[3] += a[3] * f[ww];
                 }
             } else {
                 v[0] = m;
 #pragma unroll
-                for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) v[1] += sm[(ww * 16 + i) * PSTRIDE + HD + 1] * f[ww];   // the running sum l
+                for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) v[1] += sm[(ww * 16 + i) * LS + HD + 1] * f[ww];   // the running sum l
             }
             const unsigned long long lo = (unsigned long long)__builtin_bit_cast(unsigned, v[0]) | ((unsigned long long)__builtin_bit_cast(unsigned, v[1]) << 32);
             const unsigned long long hi = (unsigned long long)__builtin_bit_cast(unsigned, v[2]) | ((unsigned long long)__builtin_bit_cast(unsigned, v[3]) << 32);
@@ -396,17 +405,23 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
 #endif
 }
 
-template <int HD>
+template <int HD, bool FUSED>
 __global__ __launch_bounds__(LSK_ATTN_THREADS) void lsk_attn_split_kernel(const elem_t* q, const elem_t* kpool, const elem_t* vpool,
                                                                            const int* block_table, const int* kv_len, int ldq, int geom,
                                                                            int rows, int pos_off, const AttnSplitParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[lsk_attn_lds_bytes<HD>()];
     const AttnHot hp{q, kpool, vpool, block_table, kv_len, ldq, geom, rows, pos_off};
-    lsk_attn_body<HD>(hp, p, blockIdx.x, blockIdx.y, lds);
+    lsk_attn_body<HD, FUSED>(hp, p, blockIdx.x, blockIdx.y, lds);
+}
+typedef void (*lsk_attn_split_fn)(const elem_t*, const elem_t*, const elem_t*, const int*, const int*, int, int, int, int, const AttnSplitParams);
+// the instantiation of a launch: head size x (single-kernel form = the block carries arrival counters)
+static inline lsk_attn_split_fn lsk_attn_split_for(int head_dim, bool fused) {
+    if (head_dim == 128) return fused ? lsk_attn_split_kernel<128, true> : lsk_attn_split_kernel<128, false>;
+    return fused ? lsk_attn_split_kernel<64, true> : lsk_attn_split_kernel<64, false>;
 }
 // the explicit-argument list of a launch, from the block
 #define LSK_ATTN_HOT_ARGS(sp) (sp).q, (sp).kpool, (sp).vpool, (sp).block_table, (sp).kv_len, (sp).ldq, ((sp).n_kv | ((sp).group << 16)), \
-                              ((sp).M | ((sp).heads_per_wg << 8) | ((sp).inv_m << 16)), (sp).pos_off, (sp)
+                              ((sp).M | ((sp).heads_per_wg << 8) | ((sp).inv_m << 16) | ((sp).identity_table ? (1 << 30) : 0)), (sp).pos_off, (sp)
 
 template <int HD>
 __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineParams p) {

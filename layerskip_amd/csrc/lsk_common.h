@@ -69,6 +69,29 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+// All-reduce over the 4 lanes {c, c + 16, c + 32, c + 48} of a wave (one column of an MFMA C tile lives in these 4 lanes' registers):
+// gfx950's row swaps.  v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second; fed two copies of a value, each leaves (even
+// partner, odd partner) of every lane in the two registers, so all 4 lanes combine the same operands in the same order and end
+// with bit-identical results.  (Inline assembly: the builtin of this toolchain loses the second result; the s_nop covers the
+// VALU-write -> permlane-read hazard the compiler can no longer see.)
+__device__ __forceinline__ void lsk_row_swap16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lsk_row_swap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float col4_max(float v) {
+    float a = v, b = v;
+    lsk_row_swap16(a, b);
+    a = fmaxf(a, b); b = a;
+    lsk_row_swap32(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float col4_sum(float v) {
+    float a = v, b = v;
+    lsk_row_swap16(a, b);
+    a = a + b; b = a;
+    lsk_row_swap32(a, b);
+    return a + b;
+}
+
 // One step of the (value, index) maximum over a 16-lane row, lowest index wins ties (torch.argmax): the lane takes the pair of
 // the lane ROT places to its right if that is better.
 template <int ROT>

@@ -22,6 +22,7 @@ struct lsk_engine {
     StepState* state = nullptr;
     int* zero = nullptr;          // constant 0 (position base of absolute-position passes)
     int* block_table = nullptr;
+    bool block_table_identity = true;   // host mirror: logical page i is physical page i (the attention kernel then needs no table read)
     int* row_tokens = nullptr;    // [17] token of each step row (row 0 = input token, row j = draft j)
     int* verified = nullptr;      // [17]
     int* eos = nullptr;           // [8]

@@ -308,6 +308,13 @@ extern "C" int lsk_engine_set_block_table(lsk_engine* e, const int32_t* table, i
         if (table[i] < 0 || table[i] >= e->n_pages) return lsk_fail("block table entry %d out of range", i);
     HIP_OK(hipMemcpyAsync(e->block_table, table, sizeof(int) * n_pages, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    bool identity = true;
+    for (int i = 0; i < n_pages; ++i) identity = identity && table[i] == i;
+    if (identity != e->block_table_identity) {       // captured steps carry the flag in their attention launches' arguments
+        for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+        e->graphs.clear();
+    }
+    e->block_table_identity = identity;
     return 0;
 }
 
@@ -404,6 +411,7 @@ static int attn_params(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     while (hw * 2 <= sp.group && hw * 2 * m <= LSK_MAX_ROWS && sp.group % (hw * 2) == 0) hw *= 2;
     sp.heads_per_wg = hw;
     sp.inv_m = (256 + m - 1) / m;
+    sp.identity_table = e->block_table_identity ? 1 : 0;
     return 0;
 }
 
@@ -420,11 +428,9 @@ static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     hipEvent_t ea = nullptr, eb = nullptr;
     // algorithmic bytes: K and V of every key in reach, once (GQA: each KV head once)
     LSK_TRY(profile_pair(e, LSK_PROF_ATTN, m, 2.0 * 2.0 * c.n_kv_heads * hd * (double)(e->kv_len_host + pos_off + m), &ea, &eb));
-    if (ea != nullptr) {
-        if (hd == 128) hipExtLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, ea, eb, 0, LSK_ATTN_HOT_ARGS(sp));
-        else hipExtLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, ea, eb, 0, LSK_ATTN_HOT_ARGS(sp));
-    } else if (hd == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, LSK_ATTN_HOT_ARGS(sp));
-    else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, LSK_ATTN_HOT_ARGS(sp));
+    const lsk_attn_split_fn kern = lsk_attn_split_for(hd, sp.counters != nullptr);
+    if (ea != nullptr) hipExtLaunchKernelGGL(kern, grid, block, 0, st, ea, eb, 0, LSK_ATTN_HOT_ARGS(sp));
+    else hipLaunchKernelGGL(kern, grid, block, 0, st, LSK_ATTN_HOT_ARGS(sp));
     HIP_OK(hipGetLastError());
     if (e->fused_attn) return 0;
     AttnCombineParams cp{};

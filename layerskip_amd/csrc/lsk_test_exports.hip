@@ -193,8 +193,7 @@ extern "C" int lsk_test_attention(const void* q, int32_t rows, int32_t n_heads, 
     sp.heads_per_wg = hw;
     sp.inv_m = (256 + rows - 1) / rows;
     const dim3 grid(n_heads / hw, pages), block(LSK_ATTN_THREADS);
-    if (head_dim == 128) hipLaunchKernelGGL((lsk_attn_split_kernel<128>), grid, block, 0, st, LSK_ATTN_HOT_ARGS(sp));
-    else hipLaunchKernelGGL((lsk_attn_split_kernel<64>), grid, block, 0, st, LSK_ATTN_HOT_ARGS(sp));
+    hipLaunchKernelGGL(lsk_attn_split_for(head_dim, sp.counters != nullptr), grid, block, 0, st, LSK_ATTN_HOT_ARGS(sp));
     HIP_OK(hipGetLastError());
     if (mode == 1) {
         AttnCombineParams cp{};

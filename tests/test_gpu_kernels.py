@@ -207,6 +207,28 @@ def test_paged_kv_block_table_indirection(gpu_device):
     eng.close()
 
 
+@pytest.mark.parametrize("graph_steps", [0, 1])
+def test_generation_is_identical_under_a_permuted_block_table(gpu_device, graph_steps):
+    """The attention launch skips the table read while the table is the identity (a flag in its arguments, also inside captured
+    steps): switching to a permuted table and back must take the other path each time and give the same ids."""
+    from layerskip_amd import GenerationConfig, _lib, synthetic
+    from layerskip_amd.engine import get_engine
+    from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
+    cfg = synthetic.make_config("tiny-gqa")
+    model = synthetic.build_model(cfg, seed=21, exit_layer=3, late_damping=0.1).to(gpu_device)
+    eng = get_engine(model, max_ctx=1024, max_prompt=400)
+    eng.set_option(_lib.LSK_OPT_GRAPH_STEPS, graph_steps)
+    n_pages = eng.max_ctx // eng.page_size
+    prompt = synthetic.make_prompt(cfg.vocab_size, 300, 4)
+    gen = GenerationConfig(max_steps=96, exit_layer=3, num_speculations=4, sample=False)
+    strat = HipSelfSpeculativeGenerationStrategy()
+    outs = []
+    for table in (list(range(n_pages)), [(3 * i + 1) % n_pages for i in range(n_pages)], list(range(n_pages))):
+        eng.set_block_table(table)
+        outs.append(strat.generate_token_ids(model, prompt, [cfg.vocab_size], gen).predicted_tokens)
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == 96
+
+
 def test_engine_grows_context_on_demand(gpu_device):
     from layerskip_amd import GenerationConfig, synthetic
     from layerskip_amd.engine import get_engine
