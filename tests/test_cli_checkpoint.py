@@ -288,3 +288,47 @@ def test_tied_embeddings_checkpoint_loads_with_the_head_tied(tmp_path):
     assert part.model.layers[0].mlp.up_proj.weight.device.type == "meta" and part.model.layers[2].mlp.up_proj.weight.device.type == "cpu"
     # and the partial model decodes like the whole one through the CPU stage backend (rank-style: layers [1, 3) only hold weights)
     assert torch.equal(part.model.layers[1].self_attn.q_proj.weight, model.model.layers[1].self_attn.q_proj.weight)
+
+
+def test_loader_error_paths_name_the_problem(tmp_path, ckpt):
+    """What a user gets for the checkpoints the loader cannot read: a directory without safetensors files (the reference's
+    `from_pretrained` would try .bin files), a non-Llama model type, a shard that lacks a tensor the rank owns; and the single-file
+    layout (no index) loads like the sharded one."""
+    import shutil
+    from safetensors.torch import load_file, save_file
+    from layerskip_amd.checkpoint import load_layer_range
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    shutil.copy(os.path.join(ckpt["path"], "config.json"), empty / "config.json")
+    with pytest.raises(FileNotFoundError, match="safetensors"):
+        load_layer_range(str(empty), None, device="cpu")
+
+    # one file, no index: same tensors
+    single = tmp_path / "single"
+    ckpt["model"].save_pretrained(str(single), safe_serialization=True)          # default shard size: one model.safetensors
+    assert os.path.exists(single / "model.safetensors") and not os.path.exists(single / "model.safetensors.index.json")
+    a = load_layer_range(str(single), (0, 2), device="cpu")
+    b = load_layer_range(ckpt["path"], (0, 2), device="cpu")
+    assert torch.equal(a.model.layers[1].mlp.down_proj.weight, b.model.layers[1].mlp.down_proj.weight)
+    assert a.model.layers[3].mlp.down_proj.weight.device.type == "meta"
+
+    # a tensor of an OWNED layer is gone: named in the error; a rank that does not own the layer is not affected
+    broken = tmp_path / "broken"
+    shutil.copytree(single, broken)
+    tensors = load_file(str(broken / "model.safetensors"))
+    del tensors["model.layers.1.self_attn.k_proj.weight"]
+    save_file(tensors, str(broken / "model.safetensors"), metadata={"format": "pt"})
+    with pytest.raises(KeyError, match="model.layers.1.self_attn.k_proj.weight"):
+        load_layer_range(str(broken), (0, 2), device="cpu")
+    ok = load_layer_range(str(broken), (2, 4), device="cpu")
+    assert ok.model.layers[2].self_attn.k_proj.weight.device.type == "cpu"
+
+    # not a Llama decoder
+    other = tmp_path / "other"
+    shutil.copytree(single, other)
+    cfg = json.load(open(other / "config.json"))
+    cfg["model_type"] = "gpt2"
+    cfg["architectures"] = ["GPT2LMHeadModel"]
+    json.dump(cfg, open(other / "config.json", "w"))
+    with pytest.raises((ValueError, KeyError)):
+        load_layer_range(str(other), None, device="cpu")
