@@ -33,8 +33,10 @@
 extern "C" {
 #endif
 
-#define LSK_ABI_VERSION 2   /* 2: options 4 / 6 removed, draft-block / sampled / profile-table entry points added, lsk_test_* moved to
-                             liblayerskip_hip_test.so (include/layerskip_hip_test.h), lsk_engine_weights_checksum added */
+#define LSK_ABI_VERSION 3   /* 2: options 4 / 6 removed, draft-block / sampled / profile-table entry points added, lsk_test_* moved to
+                             liblayerskip_hip_test.so (include/layerskip_hip_test.h), lsk_engine_weights_checksum added
+                             3: sample=True on the layer pipeline (lsk_draft_block_sampled, lsk_pipeline_pack_sampled,
+                             lsk_pipeline_tail_sampled, lsk_pipeline_residual, lsk_pipeline_result_words); message header 24 -> 40 words */
 #define LSK_MAX_ROWS 16
 #define LSK_MAX_SPEC 15   /* num_speculations handled by one fused step (rows = spec + 1) */
 #define LSK_MAX_EOS 8
@@ -184,7 +186,7 @@ int lsk_ar_generate(lsk_engine* e, const int32_t* input_ids, int32_t n_ids, int3
 int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows,
                     int32_t pos_off0, int32_t exit_layer, int32_t head_last, void* stream);
 /* The verify block travels rank to rank as ONE message: buffer 2 (LSK_MAX_ROWS + 1 rows), row 0 = a header of int32 words
- * {magic, go, prompt_len, rows, verified context length, draft ids[16]}, rows 1.. = the hidden rows.  No rank reads the header on
+ * {magic, go, prompt_len, rows, verified context length, draft ids[16], mode, Philox offset[2], p_i(x_i)[16]}, rows 1.. = the hidden rows.  No rank reads the header on
  * the host before it has enqueued the step:
  *   lsk_pipeline_pack  (rank 0)     step rows [src_row, src_row + m) -> message rows [1, 1 + m), header from the arguments and the
  *                                   device-resident draft tokens; go = 0: header only (the final verified length);
@@ -197,6 +199,26 @@ int lsk_engine_set_eos(lsk_engine* e, const int32_t* eos_token_ids, int32_t n_eo
 int lsk_pipeline_pack(lsk_engine* e, int32_t go, int32_t prompt_len, int32_t src_row, int32_t m, int32_t kv, void* stream);
 int lsk_pipeline_apply(lsk_engine* e, int32_t kv_bound, void* stream);
 int lsk_pipeline_tail(lsk_engine* e, int32_t m, void* result_dev, void* stream);
+/* sample=True on the layer pipeline (the reference's default, generator_base.py:39; acceptance SSG:191-199): lsk_spec_step_sampled split
+ * where its data lives.  Rank 0 drafts with lsk_draft_block_sampled (draft j of a block: Philox tag j, its warped distribution kept in the
+ * scratch's p_draft row row0 + j) and packs the header with the step's Philox offset and the S scalars p_i(x_i) (lsk_pipeline_pack_sampled);
+ * the last rank draws its verify tokens, runs the acceptance test and answers with lsk_pipeline_result_words() int32 words:
+ *   [0] num_matches, [1] num_drafts, [2] next token (-1: residual draw pending), [3] verified context length, [4..21) emitted tokens,
+ *   [21] residual pending, [22] protocol error (header offset != the last rank's step offset), [64 ..) fp32 q_n (the verify row at the
+ *   first rejection) -- ONE probability row per step instead of S of them the other way (lsk_pipeline_tail_sampled);
+ * rank 0 finishes a pending block with its own p_n: the token from max(q_n - p_n, 0) (max_fn, SSG:27-29) (lsk_pipeline_residual, a no-op on a
+ * block that is not pending).  Same Philox counters and comparisons as the one-GPU kernel: draw-for-draw the tokens of
+ * lsk_spec_generate_sampled under the same (seed, offset).  `scratch`: lsk_sampling_scratch_bytes() of device memory on each rank. */
+int lsk_pipeline_result_words(const lsk_config* cfg, int32_t* out_words);
+int lsk_draft_block_sampled(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows, int32_t pos_off0,
+                            int32_t exit_layer, int32_t head_last, float temperature, int32_t top_k, float top_p, uint64_t seed,
+                            uint64_t offset, void* scratch, size_t scratch_bytes, void* stream);
+int lsk_pipeline_pack_sampled(lsk_engine* e, int32_t go, int32_t prompt_len, int32_t src_row, int32_t m, int32_t kv, uint64_t offset,
+                              void* scratch, size_t scratch_bytes, void* stream);
+int lsk_pipeline_tail_sampled(lsk_engine* e, int32_t m, float temperature, int32_t top_k, float top_p, uint64_t seed, uint64_t offset,
+                              void* scratch, size_t scratch_bytes, void* result_dev, int32_t result_words, void* stream);
+int lsk_pipeline_residual(lsk_engine* e, void* result_dev, int32_t result_words, int32_t src_row, uint64_t seed, uint64_t offset,
+                          void* scratch, size_t scratch_bytes, void* stream);
 /* tokens of step rows [row0, row0 + n) (row 0 = the input token, row j = draft j): HOST int32[n]; synchronises */
 int lsk_get_row_tokens(lsk_engine* e, int32_t row0, int32_t n, int32_t* out, void* stream);
 /* move step rows (hidden rows + tokens) [src, src+n) down to [dst, dst+n), dst < src */

@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_uint64, c_vo
 LSK_MAX_ROWS = 16
 LSK_MAX_SPEC = 15
 LSK_MAX_EOS = 8
-LSK_ABI_VERSION = 2
+LSK_ABI_VERSION = 3
 LSK_OPT_BIG_THRESHOLD = 1
 LSK_OPT_TARGET_WGS = 2
 LSK_OPT_FUSED_ATTN = 3
@@ -76,6 +76,13 @@ PROTOTYPES = {
     "lsk_pipeline_pack": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "lsk_pipeline_apply": (c_int32, [c_void_p, c_int32, c_void_p]),
     "lsk_pipeline_tail": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "lsk_pipeline_result_words": (c_int32, [POINTER(LskConfig), POINTER(c_int32)]),
+    "lsk_draft_block_sampled": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
+                                          c_float, c_uint64, c_uint64, c_void_p, c_size_t, c_void_p]),
+    "lsk_pipeline_pack_sampled": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint64, c_void_p, c_size_t, c_void_p]),
+    "lsk_pipeline_tail_sampled": (c_int32, [c_void_p, c_int32, c_float, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_size_t, c_void_p,
+                                            c_int32, c_void_p]),
+    "lsk_pipeline_residual": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_uint64, c_uint64, c_void_p, c_size_t, c_void_p]),
     "lsk_get_row_tokens": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32), c_void_p]),
     "lsk_shift_rows": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "lsk_rows_offset": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_size_t)]),

@@ -62,13 +62,21 @@ __global__ void lsk_accept_kernel(int* __restrict__ draft, const int* __restrict
 #define LSK_HDR_ROWS 3        // valid rows of the block (num_drafts + 1)
 #define LSK_HDR_KV 4          // verified context length BEFORE this step: the previous step's rollback (crop_past_key_values)
 #define LSK_HDR_DRAFTS 5      // [16] the draft token ids (the last rank's acceptance kernel compares them with its argmaxes)
-#define LSK_HDR_WORDS 24
+#define LSK_HDR_MODE 21        // 0: greedy acceptance on the last rank; 1: sample=True (the words below are valid)
+#define LSK_HDR_OFF_LO 22      // the step's Philox offset (counter words 2-3) as rank 0 used it for the drafts: the last rank, which counts
+#define LSK_HDR_OFF_HI 23      //   steps on its own, refuses the block when the two disagree (a protocol out of step must not pass as a draw)
+#define LSK_HDR_PDRAFT 24      // [16] fp32 bit patterns: p_i(x_i), the warped draft probability of draft token i (SSG:194's denominator)
+#define LSK_HDR_WORDS 40
+#define LSK_HDR_HOST_WORDS 24  // what a host reads back of a header (magic .. the Philox offset)
 #define LSK_HDR_MAGIC_VALUE 0x4c534b31
 
 // rank 0: step rows [src_row, src_row + m) of the step buffer -> message rows [1, 1 + m); header from the arguments and the
 // device-resident draft tokens (row_tokens[src_row + 1 ...])
+// p_draft != nullptr (sample=True): mode 1, the step's Philox offset and, per draft, the probability its own warped distribution gave it
+// (row src_row + i of p_draft [16][ld]) -- all the last rank's acceptance test needs of the S draft distributions.
 __global__ void lsk_pipeline_pack_kernel(const elem_t* __restrict__ hrow, const int* __restrict__ row_tokens, int src_row, int m, int hidden,
-                                         int go, int prompt_len, int kv, elem_t* __restrict__ msg) {
+                                         int go, int prompt_len, int kv, elem_t* __restrict__ msg, const float* __restrict__ p_draft, int ld,
+                                         unsigned int off_lo, unsigned int off_hi) {
     if (blockIdx.x == 0) {
         int* hdr = (int*)msg;
         if (threadIdx.x < LSK_HDR_WORDS) {
@@ -80,6 +88,15 @@ __global__ void lsk_pipeline_pack_kernel(const elem_t* __restrict__ hrow, const 
             else if (t == LSK_HDR_ROWS) v = m;
             else if (t == LSK_HDR_KV) v = kv;
             else if (t >= LSK_HDR_DRAFTS && t < LSK_HDR_DRAFTS + m - 1) v = row_tokens[src_row + 1 + (t - LSK_HDR_DRAFTS)];
+            else if (p_draft != nullptr) {
+                if (t == LSK_HDR_MODE) v = 1;
+                else if (t == LSK_HDR_OFF_LO) v = (int)off_lo;
+                else if (t == LSK_HDR_OFF_HI) v = (int)off_hi;
+                else if (go && t >= LSK_HDR_PDRAFT && t < LSK_HDR_PDRAFT + m - 1) {
+                    const int i = t - LSK_HDR_PDRAFT;
+                    v = __builtin_bit_cast(int, p_draft[(size_t)(src_row + i) * ld + row_tokens[src_row + 1 + i]]);
+                }
+            }
             hdr[t] = v;
         }
         return;

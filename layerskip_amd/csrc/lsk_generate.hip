@@ -441,10 +441,9 @@ extern "C" int lsk_ar_generate(lsk_engine* e, const int32_t* input_ids, int32_t 
 // ---- layer-range pipeline: the rank-0 half of a step as one asynchronous call -------------------
 // The device-resident draft loop of enqueue_step without the verify: rank 0 of a layer pipeline owns layers [0, E)
 // and a copy of the head, drafts here, and streams the rows to the ranks that own the late layers.
-extern "C" int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows, int32_t pos_off0,
-                               int32_t exit_layer, int32_t head_last, void* stream) {
+static int draft_block_impl(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows, int32_t pos_off0,
+                            int32_t exit_layer, int32_t head_last, hipStream_t st, const StepSampling* sm) {
     LSK_TRY(lsk_ready(e));
-    hipStream_t st = (hipStream_t)stream;
     const lsk_config& c = e->cfg;
     const int P = prompt_len, E = exit_layer;
     if (E < 1 || E > c.num_layers) return lsk_fail("exit_layer %d out of range 1..%d", E, c.num_layers);
@@ -470,9 +469,22 @@ extern "C" int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t 
     for (int j = 0; j < n_rows; ++j) {
         elem_t* xr = e->hrow + (size_t)(row0 + j) * c.hidden;
         LSK_TRY(lsk_run_layers_dev(e, xr, 1, kvp, pos_off0 + j, 0, E, st));
-        if (j + 1 < n_rows || head_last) LSK_TRY(lsk_run_head_dev(e, xr, 1, nullptr, 0, e->row_tokens + row0 + j + 1, st, xr + c.hidden));
+        if (!(j + 1 < n_rows || head_last)) continue;
+        if (sm == nullptr) {
+            LSK_TRY(lsk_run_head_dev(e, xr, 1, nullptr, 0, e->row_tokens + row0 + j + 1, st, xr + c.hidden));
+        } else {
+            // draft j of the block is drawn with RNG tag j and leaves its warped distribution in p_draft row (row0 + j), as in enqueue_step_body
+            LSK_TRY(lsk_run_head_dev(e, xr, 1, sm->logits, sm->ld, nullptr, st));
+            LSK_TRY(launch_sample(e, sm->logits, sm->ld, 1, sm->temperature, sm->top_k, sm->top_p, sm->seed, sm->offset, j,
+                                  e->row_tokens + row0 + j + 1, sm->p_draft + (size_t)(row0 + j) * sm->ld, xr + c.hidden, st));
+        }
     }
     return 0;
+}
+
+extern "C" int lsk_draft_block(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows, int32_t pos_off0,
+                               int32_t exit_layer, int32_t head_last, void* stream) {
+    return draft_block_impl(e, input_ids, prompt_len, row0, n_rows, pos_off0, exit_layer, head_last, (hipStream_t)stream, nullptr);
 }
 
 // ---- layer-range pipeline: the verify block as ONE message per hop, its header applied on the device ----------------------
@@ -481,14 +493,19 @@ extern "C" int lsk_engine_set_eos(lsk_engine* e, const int32_t* eos_token_ids, i
     return upload_step_inputs(e, nullptr, 0, eos_token_ids, n_eos, (hipStream_t)stream);
 }
 
-extern "C" int lsk_pipeline_pack(lsk_engine* e, int32_t go, int32_t prompt_len, int32_t src_row, int32_t m, int32_t kv, void* stream) {
+static int pipeline_pack_impl(lsk_engine* e, int go, int prompt_len, int src_row, int m, int kv, const float* p_draft, int ld, uint64_t offset,
+                              hipStream_t st) {
     LSK_TRY(lsk_ready(e));
     if (m < 1 || src_row < 0 || src_row + m > LSK_MAX_ROWS) return lsk_fail("lsk_pipeline_pack: rows [%d,%d) exceed the step buffer", src_row, src_row + m);
     if (prompt_len < 0 || kv < 0 || kv > e->cfg.max_ctx) return lsk_fail("lsk_pipeline_pack: bad header values");
-    hipLaunchKernelGGL(lsk_pipeline_pack_kernel, dim3(1 + (go ? m : 0)), dim3(256), 0, (hipStream_t)stream, e->hrow, e->row_tokens, src_row, m,
-                       e->cfg.hidden, go ? 1 : 0, prompt_len, kv, e->hmsg);
+    hipLaunchKernelGGL(lsk_pipeline_pack_kernel, dim3(1 + (go ? m : 0)), dim3(256), 0, st, e->hrow, e->row_tokens, src_row, m, e->cfg.hidden,
+                       go ? 1 : 0, prompt_len, kv, e->hmsg, p_draft, ld, (unsigned int)offset, (unsigned int)(offset >> 32));
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+extern "C" int lsk_pipeline_pack(lsk_engine* e, int32_t go, int32_t prompt_len, int32_t src_row, int32_t m, int32_t kv, void* stream) {
+    return pipeline_pack_impl(e, go, prompt_len, src_row, m, kv, nullptr, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int lsk_pipeline_apply(lsk_engine* e, int32_t kv_bound, void* stream) {
@@ -622,3 +639,64 @@ extern "C" int lsk_spec_generate_sampled(lsk_engine* e, const int32_t* prompt_id
                               total_matches, total_drafts, step_drafts, step_matches, n_steps, stream, &sm);
 }
 
+
+// ---- sample=True on the layer pipeline: the sampled step of enqueue_step_body split where its data lives (lsk_sample.h) -------------
+extern "C" int lsk_pipeline_result_words(const lsk_config* cfg, int32_t* out_words) {
+    LSK_TRY(lsk_check_cfg(cfg));
+    if (!out_words) return lsk_fail("null out");
+    *out_words = LSK_PRES_QROW + sampling_ld(*cfg);
+    return 0;
+}
+
+extern "C" int lsk_draft_block_sampled(lsk_engine* e, const int32_t* input_ids, int32_t prompt_len, int32_t row0, int32_t n_rows,
+                                       int32_t pos_off0, int32_t exit_layer, int32_t head_last, float temperature, int32_t top_k, float top_p,
+                                       uint64_t seed, uint64_t offset, void* scratch, size_t scratch_bytes, void* stream) {
+    LSK_TRY(lsk_ready(e));
+    StepSampling sm;
+    LSK_TRY(make_step_sampling(e, temperature, top_k, top_p, seed, offset, scratch, scratch_bytes, &sm));
+    return draft_block_impl(e, input_ids, prompt_len, row0, n_rows, pos_off0, exit_layer, head_last, (hipStream_t)stream, &sm);
+}
+
+extern "C" int lsk_pipeline_pack_sampled(lsk_engine* e, int32_t go, int32_t prompt_len, int32_t src_row, int32_t m, int32_t kv, uint64_t offset,
+                                         void* scratch, size_t scratch_bytes, void* stream) {
+    LSK_TRY(lsk_ready(e));
+    StepSampling sm;
+    LSK_TRY(make_step_sampling(e, 1.0f, 0, 1.0f, 0, offset, scratch, scratch_bytes, &sm));
+    return pipeline_pack_impl(e, go, prompt_len, src_row, m, kv, sm.p_draft, sm.ld, offset, (hipStream_t)stream);
+}
+
+extern "C" int lsk_pipeline_tail_sampled(lsk_engine* e, int32_t m, float temperature, int32_t top_k, float top_p, uint64_t seed, uint64_t offset,
+                                         void* scratch, size_t scratch_bytes, void* result_dev, int32_t result_words, void* stream) {
+    LSK_TRY(lsk_ready(e));
+    if (m < 1 || m > LSK_MAX_ROWS || !result_dev) return lsk_fail("lsk_pipeline_tail_sampled: bad arguments");
+    if (e->n_eos_host < 0) return lsk_fail("lsk_pipeline_tail_sampled: eos list not set (lsk_engine_set_eos)");
+    StepSampling sm;
+    LSK_TRY(make_step_sampling(e, temperature, top_k, top_p, seed, offset, scratch, scratch_bytes, &sm));
+    if (result_words < LSK_PRES_QROW + sm.ld) return lsk_fail("lsk_pipeline_tail_sampled: result block of %d words, %d needed", result_words, LSK_PRES_QROW + sm.ld);
+    hipStream_t st = (hipStream_t)stream;
+    LSK_TRY(lsk_run_head_dev(e, e->hmsg + e->cfg.hidden, m, sm.logits, sm.ld, nullptr, st));
+    LSK_TRY(launch_sample(e, sm.logits, sm.ld, m, sm.temperature, sm.top_k, sm.top_p, sm.seed, sm.offset, LSK_TAG_VERIFY, e->verified, sm.p_verify,
+                          nullptr, st));
+    PipeAcceptSampledParams ap{};
+    ap.msg = e->hmsg; ap.verified = e->verified; ap.eos = e->eos; ap.n_eos = e->n_eos_host; ap.p_verify = sm.p_verify; ap.ld = sm.ld;
+    ap.seed_lo = (unsigned int)seed; ap.seed_hi = (unsigned int)(seed >> 32);
+    ap.off_lo = (unsigned int)offset; ap.off_hi = (unsigned int)(offset >> 32);
+    ap.tag_accept = LSK_TAG_ACCEPT; ap.st = e->state; ap.result = (int*)result_dev;
+    hipLaunchKernelGGL(lsk_pipeline_accept_sampled_kernel, dim3(1), dim3(LSK_SAMPLE_THREADS), 0, st, ap);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lsk_pipeline_residual(lsk_engine* e, void* result_dev, int32_t result_words, int32_t src_row, uint64_t seed, uint64_t offset,
+                                     void* scratch, size_t scratch_bytes, void* stream) {
+    LSK_TRY(lsk_ready(e));
+    if (!result_dev || src_row < 0 || src_row >= LSK_MAX_ROWS) return lsk_fail("lsk_pipeline_residual: bad arguments");
+    StepSampling sm;
+    LSK_TRY(make_step_sampling(e, 1.0f, 0, 1.0f, seed, offset, scratch, scratch_bytes, &sm));
+    if (result_words < LSK_PRES_QROW + sm.ld) return lsk_fail("lsk_pipeline_residual: result block of %d words, %d needed", result_words, LSK_PRES_QROW + sm.ld);
+    hipLaunchKernelGGL(lsk_pipeline_residual_kernel, dim3(1), dim3(LSK_SAMPLE_THREADS), 0, (hipStream_t)stream, (int*)result_dev,
+                       sm.p_draft + (size_t)src_row * sm.ld, sm.ld, e->cfg.vocab, e->row_tokens + src_row + 1, (unsigned int)seed,
+                       (unsigned int)(seed >> 32), (unsigned int)offset, (unsigned int)(offset >> 32), LSK_TAG_RESIDUAL);
+    HIP_OK(hipGetLastError());
+    return 0;
+}

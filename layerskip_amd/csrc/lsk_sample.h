@@ -861,6 +861,32 @@ __global__ __launch_bounds__(256) void lsk_sample_pick2_kernel(const SampleTwoLe
     for (int i = threadIdx.x; i < b.s.hidden / 8; i += 256) dst[i] = src[i];
 }
 
+// Gumbel-max draw from max(q - p, 0) (max_fn, SSG:27-29; normalisation-free): the whole workgroup (LSK_SAMPLE_THREADS) takes part,
+// every thread returns the same index, 0x7fffffff when q <= p everywhere.  Shared by the one-GPU acceptance kernel and by rank 0 of the
+// layer pipeline (which holds p_n and receives q_n from the last rank): same stream, same arithmetic, same token.
+__device__ __forceinline__ int lsk_residual_draw(const float* __restrict__ q, const float* __restrict__ pd, int vocab, int tag_residual,
+                                                 unsigned int off_lo, unsigned int off_hi, unsigned int seed_lo, unsigned int seed_hi,
+                                                 float* red, int* redi) {
+    const int tid = threadIdx.x;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    const int groups = (vocab + 3) >> 2;
+    for (int gq = tid; gq < groups; gq += LSK_SAMPLE_THREADS) {
+        unsigned int rnd[4];
+        lsk_philox4x32_10((unsigned int)gq, (unsigned int)tag_residual, off_lo, off_hi, seed_lo, seed_hi, rnd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = gq * 4 + j;
+            if (i < vocab) {
+                const float w = q[i] - pd[i];
+                const float s = (w > 0.f) ? __logf(w) + lsk_gumbel(rnd[j]) : -INFINITY;
+                if (s > best || (s == best && i < best_i)) { best = s; best_i = i; }
+            }
+        }
+    }
+    return block_argmax(best, best_i, red, redi);
+}
+
 struct AcceptSampledParams {
     int* draft;                 // row_tokens + 1 (draft[-1] receives the next input token)
     int* verified;              // [num_drafts + 1] tokens sampled from the verify rows; position n is overwritten on a rejection
@@ -906,26 +932,8 @@ __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_accept_sampled_kernel(
     const int td = s_td, n = s_n;
     int next;
     if (n < td) {
-        // Gumbel-max draw from max(q - p, 0) of row n
-        const float* q = p.p_verify + (size_t)n * p.ld;
-        const float* pd = p.p_draft + (size_t)n * p.ld;
-        float best = -INFINITY;
-        int best_i = 0x7fffffff;
-        const int groups = (p.vocab + 3) >> 2;
-        for (int gq = tid; gq < groups; gq += LSK_SAMPLE_THREADS) {
-            unsigned int rnd[4];
-            lsk_philox4x32_10((unsigned int)gq, (unsigned int)p.tag_residual, p.off_lo, p.off_hi, p.seed_lo, p.seed_hi, rnd);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = gq * 4 + j;
-                if (i < p.vocab) {
-                    const float w = q[i] - pd[i];
-                    const float s = (w > 0.f) ? __logf(w) + lsk_gumbel(rnd[j]) : -INFINITY;
-                    if (s > best || (s == best && i < best_i)) { best = s; best_i = i; }
-                }
-            }
-        }
-        next = block_argmax(best, best_i, red, redi);
+        next = lsk_residual_draw(p.p_verify + (size_t)n * p.ld, p.p_draft + (size_t)n * p.ld, p.vocab, p.tag_residual, p.off_lo, p.off_hi,
+                                 p.seed_lo, p.seed_hi, red, redi);
         if (next == 0x7fffffff) next = p.draft[n];   // q == p on the whole row: cannot be reached through a rejection
     } else {
         next = p.verified[td];
@@ -949,5 +957,93 @@ __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_accept_sampled_kernel(
         }
         p.result[3] = kv;
         p.result[LSK_RES_EMIT + n] = next;
+    }
+}
+
+// ---- sample=True on the layer pipeline (SURVEY 8e x 8f N2) -----------------------------------------------------------------------
+// The one-GPU acceptance kernel above needs, per draft i, the two scalars q_i(x_i) and p_i(x_i), and at the first rejection the two
+// ROWS q_n and p_n.  On the pipeline p lives on rank 0 (the draft loop) and q on the last rank (the verify head), so the test is split
+// where the data is: the S scalars p_i(x_i) travel in the header; the last rank draws its S+1 verify tokens, runs the acceptance test
+// and returns {n, td, bonus token | "residual pending"} followed by ONE probability row -- q_n -- in the same message; rank 0 then
+// draws from max(q_n - p_n, 0) with its own p_n (lsk_pipeline_residual_kernel).  Same Philox counters, same comparisons, same
+// Gumbel-max as lsk_accept_sampled_kernel: the pipeline's sampled generation is draw for draw the one-GPU one.
+// Result block (int32 words): [0] num_matches, [1] num_drafts, [2] next token (-1 while the residual draw is pending), [3] verified
+// context length, [4..21) emitted tokens, [21] residual pending, [22] protocol error (the header's Philox offset is not the last
+// rank's), [64 .. 64 + ld) fp32 q_n.
+#define LSK_PRES_PENDING 21
+#define LSK_PRES_ERROR 22
+#define LSK_PRES_QROW 64
+
+struct PipeAcceptSampledParams {
+    const elem_t* msg;          // the message buffer: row 0 = header
+    const int* verified;        // [rows] tokens drawn from the verify rows
+    const int* eos;
+    int n_eos;
+    const float* p_verify;      // [rows][ld]
+    int ld;
+    unsigned int seed_lo, seed_hi;
+    unsigned int off_lo, off_hi;
+    int tag_accept;
+    StepState* st;
+    int* result;                // LSK_PRES_QROW + ld words
+};
+
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_pipeline_accept_sampled_kernel(const PipeAcceptSampledParams p) {
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int* hdr = (const int*)p.msg;
+    if (tid == 0) {
+        const int num_drafts = min(max(hdr[LSK_HDR_ROWS], 1), LSK_ROWS) - 1;
+        const int* draft = hdr + LSK_HDR_DRAFTS;
+        const bool out_of_step = hdr[LSK_HDR_MODE] != 1 || (unsigned int)hdr[LSK_HDR_OFF_LO] != p.off_lo || (unsigned int)hdr[LSK_HDR_OFF_HI] != p.off_hi;
+        int td = num_drafts;
+        for (int i = 0; i < num_drafts && td == num_drafts; ++i)
+            for (int k = 0; k < p.n_eos; ++k)
+                if (draft[i] == p.eos[k]) { td = i + 1; break; }       // a drafted EOS ends the draft (SSG:146-148)
+        int n = 0;
+        for (int i = 0; i < td; ++i) {
+            const float q = p.p_verify[(size_t)i * p.ld + draft[i]];
+            const float pd = __builtin_bit_cast(float, hdr[LSK_HDR_PDRAFT + i]);
+            unsigned int rnd[4];
+            lsk_philox4x32_10((unsigned int)i, (unsigned int)p.tag_accept, p.off_lo, p.off_hi, p.seed_lo, p.seed_hi, rnd);
+            if (lsk_u01(rnd[0]) < fminf(1.0f, q / pd)) ++n; else break;
+        }
+        s_n = n;
+        const int next = (n == td) ? p.verified[td] : -1;
+        for (int i = 0; i < n; ++i) p.result[LSK_RES_EMIT + i] = draft[i];
+        p.result[LSK_RES_EMIT + n] = next;
+        p.result[0] = n;
+        p.result[1] = td;
+        p.result[2] = next;
+        const int kv = p.st->kv_len + hdr[LSK_HDR_P] + n;
+        p.st->kv_len = kv;
+        p.st->next_token = next;
+        p.result[3] = kv;
+        p.result[LSK_PRES_PENDING] = (n < td) ? 1 : 0;
+        p.result[LSK_PRES_ERROR] = out_of_step ? 1 : 0;
+    }
+    __syncthreads();
+    // q_n behind the result words: the one probability row rank 0 needs (all drafts kept: row td, unused but defined)
+    const float* q = p.p_verify + (size_t)s_n * p.ld;
+    float* dst = (float*)(p.result + LSK_PRES_QROW);
+    for (int i = tid; i < p.ld; i += LSK_SAMPLE_THREADS) dst[i] = q[i];
+}
+
+// rank 0: finish a received result block whose residual draw is pending -- the token from max(q_n - p_n, 0), with the p_n of ITS draft loop
+__global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_pipeline_residual_kernel(int* __restrict__ blk, const float* __restrict__ p_draft, int ld, int vocab,
+                                                                                   const int* __restrict__ draft, unsigned int seed_lo, unsigned int seed_hi,
+                                                                                   unsigned int off_lo, unsigned int off_hi, int tag_residual) {
+    __shared__ float red[LSK_SAMPLE_WAVES];
+    __shared__ int redi[LSK_SAMPLE_WAVES];
+    if (!blk[LSK_PRES_PENDING]) return;                       // uniform over the workgroup
+    const int n = min(max(blk[0], 0), LSK_ROWS - 1);
+    int next = lsk_residual_draw((const float*)(blk + LSK_PRES_QROW), p_draft + (size_t)n * ld, vocab, tag_residual, off_lo, off_hi, seed_lo, seed_hi,
+                                 red, redi);
+    if (next == 0x7fffffff) next = draft[n];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk[2] = next;
+        blk[LSK_RES_EMIT + n] = next;
+        blk[LSK_PRES_PENDING] = 0;
     }
 }

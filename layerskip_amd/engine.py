@@ -485,6 +485,69 @@ class HipEngine:
         self._ck(self.lib.lsk_pipeline_tail(self._handle, int(m), res.data_ptr(), self._stream))
         return res
 
+    # ---- sample=True on the pipeline (lsk_draft_block_sampled / lsk_pipeline_pack_sampled / _tail_sampled / _residual) ----
+    def pipeline_result_words(self) -> int:
+        """int32 words of a sampled step's result block: 64 result words + one fp32 probability row (q_n)."""
+        n = ctypes.c_int32(0)
+        self._ck(self.lib.lsk_pipeline_result_words(ctypes.byref(self.cfg), ctypes.byref(n)))
+        return n.value
+
+    def draft_block_sampled(self, input_ids: Optional[Sequence[int]], row0: int, n_rows: int, pos_off0: int, exit_layer: int,
+                            head_last: bool, temperature: float, top_k: int, top_p: float, seed: int, offset: int) -> None:
+        """`draft_block` with every argmax replaced by a draw (draft j of the block: Philox tag j at `offset`); the warped draft
+        distributions stay in the sampling scratch (rows row0 + j) for `pipeline_pack_sampled` / `pipeline_residual`."""
+        if input_ids is None:
+            ids, n = None, 1
+        else:
+            ids, n = _i32_array(input_ids), len(input_ids)
+        scratch = self._sampling_scratch()
+        self._ck(self.lib.lsk_draft_block_sampled(self._handle, ids, n, int(row0), int(n_rows), int(pos_off0), int(exit_layer),
+                                               1 if head_last else 0, float(temperature), int(top_k), float(top_p),
+                                               int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), scratch.data_ptr(), scratch.numel(),
+                                               self._stream))
+
+    def pipeline_pack_sampled(self, go: int, prompt_len: int, src_row: int, m: int, kv: int, offset: int) -> None:
+        """`pipeline_pack` + the sampled step's header words: mode, Philox offset, p_i(x_i) of every draft."""
+        scratch = self._sampling_scratch()
+        self._ck(self.lib.lsk_pipeline_pack_sampled(self._handle, int(go), int(prompt_len), int(src_row), int(m), int(kv),
+                                                 int(offset) & (2 ** 64 - 1), scratch.data_ptr(), scratch.numel(), self._stream))
+
+    def pipeline_tail_sampled(self, m: int, temperature: float, top_k: int, top_p: float, seed: int, offset: int) -> torch.Tensor:
+        """Last rank, sample=True: head + verify draws + the acceptance test against the header's p_i(x_i) -> device int32
+        [pipeline_result_words()] = result words + the verify row q_n at the first rejection."""
+        words = self.pipeline_result_words()
+        res = self._buffers.get("pp_result_sampled")
+        if res is None or res.numel() != words:
+            res = torch.zeros(words, dtype=torch.int32, device=self.device)
+            self._buffers["pp_result_sampled"] = res
+        scratch = self._sampling_scratch()
+        self._ck(self.lib.lsk_pipeline_tail_sampled(self._handle, int(m), float(temperature), int(top_k), float(top_p),
+                                                 int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), scratch.data_ptr(), scratch.numel(),
+                                                 res.data_ptr(), words, self._stream))
+        return res
+
+    def pipeline_residual(self, block: torch.Tensor, src_row: int, seed: int, offset: int) -> None:
+        """Rank 0: finish a sampled result block in place -- if its residual draw is pending, the token from max(q_n - p_n, 0) with
+        this rank's p_n (the draft rows start at step row `src_row`)."""
+        if block.dtype != torch.int32 or block.device != self.device or not block.is_contiguous():
+            raise _lib.LskError("the result block must be a contiguous int32 tensor on the engine device")
+        scratch = self._sampling_scratch()
+        self._ck(self.lib.lsk_pipeline_residual(self._handle, block.data_ptr(), block.numel(), int(src_row), int(seed) & (2 ** 64 - 1),
+                                             int(offset) & (2 ** 64 - 1), scratch.data_ptr(), scratch.numel(), self._stream))
+
+    def logits_rows(self, blocks: Sequence[Sequence[int]]) -> torch.Tensor:
+        """Final norm + lm_head logits of the listed (buffer, row_base, count) blocks -> [rows, vocab] in the model dtype (the values
+        the reference's `model.lm_head` returns, LMU:273, :387): what logits processors are shown."""
+        total = sum(c for _, _, c in blocks)
+        out = torch.empty(total, self.vocab, dtype=torch.float32, device=self.device)
+        at = 0
+        for buf, base, count in blocks:
+            for r0 in range(0, count, _lib.LSK_MAX_ROWS):
+                m = min(_lib.LSK_MAX_ROWS, count - r0)
+                self.run_head(buf, base + r0, m, logits=out[at:at + m], want_tokens=False)
+                at += m
+        return out.to(self.dtype)
+
     def header(self) -> List[int]:
         """The int32 words of the message header (synchronises: a device -> host read)."""
         return [int(v) for v in self.rows_view(BUF_MSG, 0, 1).view(torch.int32)[0, :24].tolist()]

@@ -92,16 +92,37 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         self.device_sampling = device_sampling
         self._sample_base = None
         self._sample_step = 0
+        self._stream_fresh = False        # generate_token_ids has just started a stream: its first step must not start another
         # fused_generate: greedy generations without processors / criteria / streamer run as ONE C-ABI call
         # (lsk_spec_generate: the loop of SSG:51-95 with the steps pipelined on the stream)
         self.fused_generate = fused_generate
         self.last_steps = []              # [(num_drafts, num_matches)] of the last fused generation
 
+    # ------------------------------------------------------------------------------ where the engine and the late layers live
+    # (one GPU: here.  The layer pipeline's slow path overrides the three: rank 0's engine owns the early layers and a head, the late
+    #  layers and the verify head are other ranks', layerskip_amd/pipeline_strategy.py)
+    def _get_engine(self, model, check_weights: bool = True) -> HipEngine:
+        return get_engine(model, check_weights=check_weights, **self.engine_kwargs)
+
+    def _verify_logits(self, engine: HipEngine, P: int, td: int, E: int, sbuf: int, sbase: int, prompt_rows: bool) -> torch.Tensor:
+        """forward_remainder's late layers + final norm + lm_head (LMU:364-387) over the td + 1 step rows (and the P - 1 prompt rows
+        in front): logits [1, (P - 1 if prompt_rows) + td + 1, V]."""
+        L = engine.num_layers
+        if P > 1:
+            engine.run_bulk(P - 1, E, L)
+        engine.run_layers_chunked(sbuf, sbase, td + 1, P - 1, E, L)
+        blocks = ([(BUF_BULK, 0, P - 1)] if (P > 1 and prompt_rows) else []) + [(sbuf, sbase, td + 1)]
+        return self._logits_rows(engine, blocks)
+
+    def _commit(self, engine: HipEngine, kv_len: int) -> None:
+        """crop_past_key_values (SSG:219-221): the verified context length after a step."""
+        engine.set_kv_len(kv_len)
+
     # ------------------------------------------------------------------------------ outer loop
     def generate_token_ids(self, model, input_ids: List[int], eos_token_ids: List[int],
                            generation_config: GenerationConfig, logits_processors=None, stopping_criteria=None,
                            streamer=None) -> GenerationStrategyResult:
-        engine = get_engine(model, **self.engine_kwargs)
+        engine = self._get_engine(model)
         spec = max(0, int(generation_config.num_speculations))
         extra_rows = spec if spec > _lib.LSK_MAX_SPEC else 0      # long draft blocks live behind the prompt rows
         engine.ensure_capacity(len(input_ids) + generation_config.max_steps + spec + 2, len(input_ids) + extra_rows)
@@ -162,6 +183,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         """Counter base of the Philox stream of one generation: one draw from torch's global generator."""
         self._sample_base = int(torch.randint(0, 2 ** 62, (1,)).item())
         self._sample_step = 0
+        self._stream_fresh = True
 
     # ------------------------------------------------------------------------------ one step
     def single_step_speculation(self, model, input_ids: torch.Tensor, input_ids_list: List[int],
@@ -171,7 +193,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                                 top_k: Optional[int] = 50, top_p: Optional[float] = 0.95,
                                 logits_processors=None, stopping_criteria=None, streamer=None):
         # the packed weights are checked against the live model at the START of a generation, not on every step
-        engine = get_engine(model, check_weights=past_key_values is None, **self.engine_kwargs)
+        engine = self._get_engine(model, check_weights=past_key_values is None)
         if past_key_values is None:
             sp = max(0, num_speculations)
             engine.ensure_capacity(len(input_ids_list) + sp + 2, input_ids.shape[1] + (sp if sp > _lib.LSK_MAX_SPEC else 0))
@@ -183,8 +205,11 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         eos_token_ids = [t for t in eos_token_ids if t is not None]
         if (sample and self.device_sampling and not logits_processors and spec <= _lib.LSK_MAX_SPEC
                 and hasattr(engine, "spec_step_sampled")):
-            if past_key_values is None or self._sample_base is None:
-                self._new_sample_stream()          # a step called on its own (the reference's tests do) starts a stream
+            # a step called on its own (the reference's tests do) starts a stream; the first step of generate_token_ids continues the one
+            # that call drew, so the fused call, the step loop and the layer pipeline consume torch's generator identically
+            if self._sample_base is None or (past_key_values is None and not self._stream_fresh):
+                self._new_sample_stream()
+            self._stream_fresh = False
             step = engine.spec_step_sampled(new_ids, spec, exit_layer, eos_token_ids, temperature, top_k, top_p,
                                             torch.initial_seed(), self._sample_base + self._sample_step)
             self._sample_step += 1
@@ -210,7 +235,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
         # crop_past_key_values(past, len(input_ids_list) + len(output_ids) - 1): a counter write
         target = len(input_ids_list) + len(output_ids) - 1
         if target != engine.kv_len:
-            engine.set_kv_len(target)
+            self._commit(engine, target)
         return next_input, output_ids, EngineCache(engine), n, step.num_drafts
 
     # ------------------------------------------------------------------------------ slow path
@@ -229,7 +254,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
     def _slow_step(self, engine: HipEngine, ids: List[int], spec: int, exit_layer: int, eos: List[int], sample: bool,
                    temperature: float, top_k: int, top_p: float, processors):
         from .engine import StepResult
-        P, E, L = len(ids), exit_layer, engine.num_layers
+        P, E = len(ids), exit_layer
         C = engine.kv_len
         dev = engine.device
         # the step rows (input token + drafts) live in the 16-row step buffer, or -- for more than 15
@@ -270,12 +295,8 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                 engine.run_layers(SBUF, SBASE + j, 1, P - 1 + j, 0, E)
                 break
         td = len(drafts)
-        if P > 1:
-            engine.run_bulk(P - 1, E, L)
-        engine.run_layers_chunked(SBUF, SBASE, td + 1, P - 1, E, L)
         prefill = torch.tensor([ids + drafts], device=dev)
-        blocks = ([(BUF_BULK, 0, P - 1)] if (P > 1 and processors) else []) + [(SBUF, SBASE, td + 1)]
-        logits = self._logits_rows(engine, blocks)
+        logits = self._verify_logits(engine, P, td, E, SBUF, SBASE, bool(processors))
         if processors:
             logits = processors(prefill, logits)
         vlogits = logits[:, -(td + 1):, :]
@@ -295,7 +316,7 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                     resid = _residual_distribution(vprobs[i, :], draft_probs[i][0])
                     verified[n] = int(torch.multinomial(resid, num_samples=1).item())
                     break
-        engine.set_kv_len(C + P + n)
+        self._commit(engine, C + P + n)
         return StepResult(n, td, verified[n], C + P + n, drafts[:n] + [verified[n]], drafts, verified)
 
 
@@ -304,10 +325,28 @@ class HipAutoRegressiveGenerationStrategy(GenerationStrategy):
         self.engine_kwargs = engine_kwargs or {}
         self.fused_generate = fused_generate
 
+    # where the engine and the layers live (overridden by the layer pipeline's rank-0 slow path, layerskip_amd/pipeline_strategy.py)
+    def _get_engine(self, model) -> HipEngine:
+        return get_engine(model, **self.engine_kwargs)
+
+    def _forward_logits(self, engine: HipEngine, ids: List[int], layer_end: int, prompt_rows: bool) -> torch.Tensor:
+        """`forward` / `forward_early` (LMU:155-276) over the new ids: logits [1, (P - 1 if prompt_rows) + 1, V]."""
+        P = len(ids)
+        if P > 1:
+            engine.embed_rows(ids[:-1], BUF_BULK, 0)
+            engine.run_bulk(P - 1, 0, layer_end)
+        engine.embed_rows(ids[-1:], BUF_STEP, 0)
+        engine.run_layers(BUF_STEP, 0, 1, P - 1, 0, layer_end)
+        blocks = ([(BUF_BULK, 0, P - 1)] if (P > 1 and prompt_rows) else []) + [(BUF_STEP, 0, 1)]
+        return HipSelfSpeculativeGenerationStrategy._logits_rows(None, engine, blocks)
+
+    def _commit(self, engine: HipEngine, kv_len: int) -> None:
+        engine.set_kv_len(kv_len)
+
     def generate_token_ids(self, model, input_ids: List[int], eos_token_ids: List[int],
                            generation_config: GenerationConfig, logits_processors=None, stopping_criteria=None,
                            streamer=None) -> GenerationStrategyResult:
-        engine = get_engine(model, **self.engine_kwargs)
+        engine = self._get_engine(model)
         engine.ensure_capacity(len(input_ids) + generation_config.max_steps + 10, len(input_ids))
         engine.reset()
         eos_token_ids = [t for t in eos_token_ids if t is not None]
@@ -345,17 +384,11 @@ class HipAutoRegressiveGenerationStrategy(GenerationStrategy):
                    cfg: GenerationConfig, processors) -> torch.Tensor:
         P = len(ids)
         C = engine.kv_len
-        if P > 1:
-            engine.embed_rows(ids[:-1], BUF_BULK, 0)
-            engine.run_bulk(P - 1, 0, layer_end)
-        engine.embed_rows(ids[-1:], BUF_STEP, 0)
-        engine.run_layers(BUF_STEP, 0, 1, P - 1, 0, layer_end)
-        blocks = ([(BUF_BULK, 0, P - 1)] if (P > 1 and processors) else []) + [(BUF_STEP, 0, 1)]
-        logits = HipSelfSpeculativeGenerationStrategy._logits_rows(None, engine, blocks)
+        logits = self._forward_logits(engine, ids, layer_end, bool(processors))
         if processors:
             logits = processors(ids_t.to(engine.device), logits)
         tok, _ = decode_rows(logits, True, cfg.sample, cfg.temperature, cfg.top_k, cfg.top_p)
-        engine.set_kv_len(C + P)
+        self._commit(engine, C + P)
         return tok.reshape(-1)[:1].cpu()
 
 

@@ -27,6 +27,19 @@ This module is the MI355X-native form of that partition (SURVEY.md section 8e, B
   continuation is discarded (its early-layer KV entries sit beyond the verified length and are overwritten).  Greedy
   output is unchanged either way: the continuation rows are exactly what the next step would have computed.
 
+* SAMPLING (`sample=True`, the reference's default, generator_base.py:39; acceptance SSG:191-199) keeps the same message
+  flow.  Modified rejection sampling needs, per draft, the two scalars q_i(x_i) and p_i(x_i), and at the first rejection the
+  rows q_n and p_n; p lives on rank 0, q on the last rank.  So the header carries the step's Philox offset and the S scalars
+  p_i(x_i); the last rank draws its verify tokens, runs the acceptance test (`lsk_pipeline_tail_sampled`) and answers with
+  the result words followed by ONE probability row, q_n (128 KB at V = 32 000, 513 KB at 128 256; one direct message to
+  rank 0, not through the chain); rank 0 draws the residual token from max(q_n - p_n, 0) with its own p_n
+  (`lsk_pipeline_residual`).  Same counters and comparisons as the one-GPU kernel: under the same (seed, offset) the
+  pipeline's sampled generation is DRAW FOR DRAW `lsk_spec_generate_sampled`'s.
+* LOGITS PROCESSORS (`no_repeat_ngram_size`, generator_base.py:77-85; called at SSG:138-139, :172-173) are host callables
+  on full logits rows: rank 0 runs the draft loop row by row on its own head (`hip_strategies.slow_step`), and for the verify
+  the last rank sends the logits rows back instead of running an acceptance kernel (`remote_verify`); the decisions are then
+  the one-GPU slow path's, on rank 0.
+
 One sequence is a serial draft -> verify chain, so the pipeline buys capacity (a model beyond one GPU's HBM) and
 hides only what the optimistic guess gets right; independent requests scale as replicas (bench.py reports both).
 All ranks call `generate` collectively: rank 0 broadcasts (prompt length, speculations, max_steps, eos ids), EVERY rank
@@ -49,9 +62,38 @@ BUF_MSG = 2         # row 0 = header (int32 words), rows 1.. = the verify block
 _MAX_ROWS = 16
 _MAX_EOS = 8
 _RES_WORDS = 24     # of the result block: num_matches, num_drafts, next token, context length, emitted[17]
-# header words (layerskip_amd/csrc/lsk_accept.h)
-HDR_MAGIC, HDR_GO, HDR_P, HDR_ROWS, HDR_KV, HDR_DRAFTS, HDR_WORDS = 0, 1, 2, 3, 4, 5, 24
+RES_PENDING, RES_ERROR = 21, 22     # sampled result block (csrc/lsk_sample.h): residual draw pending, protocol error
+# header words (layerskip_amd/csrc/lsk_accept.h); a host reads the first HDR_WORDS back
+HDR_MAGIC, HDR_GO, HDR_P, HDR_ROWS, HDR_KV, HDR_DRAFTS, HDR_MODE, HDR_OFF_LO, HDR_OFF_HI, HDR_WORDS = 0, 1, 2, 3, 4, 5, 21, 22, 23, 24
 HDR_MAGIC_VALUE = 0x4C534B31
+MODE_GREEDY, MODE_SAMPLED, MODE_LOGITS = 0, 1, 2      # what the last rank does with a verify block
+_META_WORDS = 4 + _MAX_EOS + 6
+
+
+@dataclass
+class Sampling:
+    """sample=True parameters of one generation (GenerationConfig temperature / top_k / top_p, generator_base.py:35-44) and its
+    Philox stream: key = seed, step i draws at counter offset `offset + i` (the contract of lsk_spec_generate_sampled)."""
+    temperature: float
+    top_k: int
+    top_p: float
+    seed: int
+    offset: int
+
+
+def _f64_bits(x: float) -> int:
+    import struct
+    return struct.unpack("<q", struct.pack("<d", float(x)))[0]
+
+
+def _bits_f64(v: int) -> float:
+    import struct
+    return struct.unpack("<d", struct.pack("<q", int(v)))[0]
+
+
+def _u64_to_i64(v: int) -> int:
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
 
 
 def plan_partition(num_layers: int, exit_layer: int, world: int, balance: str = "draft") -> List[Tuple[int, int]]:
@@ -138,12 +180,12 @@ class PipelineSpeculativeDecoder:
             dist.recv(t, src=src, group=self.group)
             self.be.write_rows(buffer, row_base, t)
 
-    def _agree(self, prompt_ids, eos_token_ids, max_steps: int, S: int):
+    def _agree(self, prompt_ids, eos_token_ids, max_steps: int, S: int, mode: int = MODE_GREEDY, sampling: Optional[Sampling] = None):
         """Collective set-up: rank 0's (P, S, max_steps, eos ids) reach every rank, every rank sizes its engine for the WHOLE
         generation (rank 0's optimistic continuation writes up to 2S+2 positions past the verified length; the stop message
         makes the late ranks run one block on stale rows), and all ranks learn whether all of them could."""
         be = self.be
-        meta = torch.zeros(4 + _MAX_EOS, dtype=torch.int64)
+        meta = torch.zeros(_META_WORDS, dtype=torch.int64)
         if self.rank == 0 and prompt_ids is None:
             meta[0] = -1                      # shutdown(): the serve loops of the other ranks end
         elif self.rank == 0:
@@ -152,6 +194,10 @@ class PipelineSpeculativeDecoder:
             # raising here would leave the other ranks waiting in the broadcast)
             meta[:4] = torch.tensor([len(prompt_ids), S, max_steps, len(eos)])
             meta[4:4 + min(len(eos), _MAX_EOS)] = torch.tensor(eos[:_MAX_EOS], dtype=torch.int64)
+            meta[4 + _MAX_EOS] = mode
+            if sampling is not None:
+                meta[5 + _MAX_EOS:] = torch.tensor([int(sampling.top_k), _u64_to_i64(sampling.seed), _u64_to_i64(sampling.offset),
+                                                    _f64_bits(sampling.temperature), _f64_bits(sampling.top_p)], dtype=torch.int64)
         if self.world > 1:
             meta = meta.to(self.dev)
             dist.broadcast(meta, src=0, group=self.group)
@@ -160,6 +206,11 @@ class PipelineSpeculativeDecoder:
         if P == -1:
             return None
         eos = [int(v) for v in meta[4:4 + min(n_eos, _MAX_EOS)].tolist()]
+        tail = [int(v) for v in meta[4 + _MAX_EOS:].tolist()]
+        mode = tail[0]
+        sampling = None
+        if mode == MODE_SAMPLED:
+            sampling = Sampling(_bits_f64(tail[4]), tail[1], _bits_f64(tail[5]), tail[2] & ((1 << 64) - 1), tail[3] & ((1 << 64) - 1))
         err = None
         try:
             if n_eos > _MAX_EOS:
@@ -168,6 +219,10 @@ class PipelineSpeculativeDecoder:
                 raise ValueError("num_speculations too large for the 16-row verify block")
             if max_steps < 1 or P < 1:
                 raise ValueError("max_steps and the prompt length must be at least 1")
+            if mode not in (MODE_GREEDY, MODE_SAMPLED, MODE_LOGITS):
+                raise ValueError(f"unknown pipeline mode {mode}")
+            if mode == MODE_SAMPLED and not hasattr(be, "pipeline_tail_sampled"):
+                raise ValueError("this stage backend cannot sample")
             be.ensure_capacity(P + max_steps + 2 * S + 2 + _MAX_ROWS, P)
             be.reset()
             be.set_eos(eos)
@@ -181,14 +236,15 @@ class PipelineSpeculativeDecoder:
                                    else "pipeline set-up failed on another rank (capacity / configuration); nothing was started")
         elif err is not None:
             raise err
-        return P, S, max_steps, eos
+        return P, S, max_steps, eos, mode, sampling
 
     # ------------------------------------------------------------------ the late ranks: serve verify blocks until told to stop
-    def _serve(self, P0: int, S: int) -> None:
+    def _serve(self, P0: int, S: int, mode: int = MODE_GREEDY, sampling: Optional[Sampling] = None) -> None:
         be = self.be
         last = self.rank == self.world - 1
         bound = 0                       # host-side UPPER bound of the verified context before the step being served
         p = P0                          # new tokens in front of the block: the prompt on the first step, 1 afterwards
+        step = 0                        # blocks served: a sampled step draws at Philox offset `sampling.offset + step`
         while True:
             t0 = time.perf_counter()
             if p > 1:
@@ -202,6 +258,15 @@ class PipelineSpeculativeDecoder:
                 if p > 1:
                     self._rows_out(BUF_BULK, 0, p - 1, self.rank + 1)
                 self._rows_out(BUF_MSG, 0, S + 2, self.rank + 1)
+            elif mode == MODE_LOGITS:
+                # logits processors decide on rank 0: the rows' logits go back instead of an acceptance result (LMU:386-387: the
+                # reference's forward_remainder returns logits for every input row, the prompt rows of the first step included)
+                rows = be.logits_rows(([(BUF_BULK, 0, p - 1)] if p > 1 else []) + [(BUF_MSG, 1, S + 1)])
+                dist.send(rows if self.direct else rows.to(self.dev), dst=0, group=self.group)
+            elif mode == MODE_SAMPLED:
+                res = be.pipeline_tail_sampled(S + 1, sampling.temperature, sampling.top_k, sampling.top_p, sampling.seed,
+                                               sampling.offset + step)
+                dist.send(res if self.direct else res.to(self.dev), dst=0, group=self.group)
             else:
                 res = be.pipeline_tail(S + 1)                # head + argmax + acceptance kernel -> device result block
                 dist.send(res[:_RES_WORDS] if self.direct else res[:_RES_WORDS].to(self.dev), dst=0, group=self.group)
@@ -221,39 +286,72 @@ class PipelineSpeculativeDecoder:
                 raise RuntimeError(f"rank {self.rank}: header says {hdr[HDR_P]} new tokens, expected {p}")
             bound = hdr[HDR_KV] + p + S                      # the next block's rollback cannot exceed this
             p = 1
+            step += 1
 
     # ------------------------------------------------------------------ rank 0: ship one verify block / fetch its result
-    def _ship(self, P: int, m: int, kv: int, row_base: int):
+    def _ship(self, P: int, m: int, kv: int, row_base: int, offset: Optional[int] = None):
         """Rank 0's own late layers (if it owns any) over step rows [row_base, row_base + m) and the prompt rows, then the block
-        into the message buffer.  One rank: the tail (head + acceptance kernel) runs here; otherwise the block leaves."""
+        into the message buffer.  One rank: the tail (head + acceptance kernel) runs here; otherwise the block leaves.
+        offset: the Philox offset of a sampled step (the header then carries it and the drafts' own probabilities)."""
         be, E = self.be, self.E
         if self.le > E:
             if P > 1:
                 be.run_bulk(P - 1, E, self.le)
             be.run_layers(BUF_STEP, row_base, m, P - 1, E, self.le)
-        be.pipeline_pack(1, P, row_base, m, kv)
+        if self._mode == MODE_SAMPLED:
+            be.pipeline_pack_sampled(1, P, row_base, m, kv, offset)
+        else:
+            be.pipeline_pack(1, P, row_base, m, kv)
         if self.world == 1:
+            if self._mode == MODE_SAMPLED:
+                sm = self._sampling
+                return be.pipeline_tail_sampled(m, sm.temperature, sm.top_k, sm.top_p, sm.seed, offset)
+            if self._mode == MODE_LOGITS:
+                return be.logits_rows(([(BUF_BULK, 0, P - 1)] if P > 1 else []) + [(BUF_MSG, 1, self._S + 1)])
             return be.pipeline_tail(m)
         if P > 1:
             self._rows_out(BUF_BULK, 0, P - 1, 1)
         self._rows_out(BUF_MSG, 0, self._S + 2, 1)
         self._inflight += 1                        # the last rank answers every message with one result block
+        self._inflight_rows = (P - 1) + self._S + 1
         return None
 
-    def _result(self, local) -> List[int]:
-        if local is not None:
-            return [int(v) for v in local[:_RES_WORDS].tolist()]
-        t = torch.zeros(_RES_WORDS, dtype=torch.int32, device=self.dev)
+    def _answer(self) -> torch.Tensor:
+        """Receive the last rank's answer to the message in flight, as it comes: greedy 24 int32 words, sampled the result words +
+        q_n, logits mode (new tokens - 1) + S + 1 rows of V logits in the model dtype."""
+        be = self.be
+        if self._mode == MODE_LOGITS:
+            t = torch.zeros(self._inflight_rows, be.vocab, dtype=getattr(be, "dtype", torch.float32), device=self.dev)
+        elif self._mode == MODE_SAMPLED:
+            t = torch.zeros(be.pipeline_result_words(), dtype=torch.int32, device=self.dev)
+        else:
+            t = torch.zeros(_RES_WORDS, dtype=torch.int32, device=self.dev)
         dist.recv(t, src=self.world - 1, group=self.group)
         self._inflight -= 1
-        return [int(v) for v in t.tolist()]
+        return t
+
+    def _result(self, local, row_base: int = 0, offset: Optional[int] = None) -> List[int]:
+        if self._mode == MODE_SAMPLED:
+            blk = local if local is not None else self._answer().to(self.be.device)
+            self.be.pipeline_residual(blk, row_base, self._sampling.seed, offset)      # no-op unless a rejection left the draw pending
+            res = [int(v) for v in blk[:_RES_WORDS].tolist()]
+            if res[RES_ERROR]:
+                raise RuntimeError("pipeline out of step: the last rank's Philox offset is not the header's")
+            return res
+        if local is not None:
+            return [int(v) for v in local[:_RES_WORDS].tolist()]
+        return [int(v) for v in self._answer().tolist()]
 
     def _stop(self, kv: int) -> None:
         """Rank 0: the stop message (header only: go = 0, the final verified length) and its answer."""
-        self.be.pipeline_pack(0, 1, 0, 1, kv)
+        if self._mode == MODE_SAMPLED:
+            self.be.pipeline_pack_sampled(0, 1, 0, 1, kv, self._sampling.offset)
+        else:
+            self.be.pipeline_pack(0, 1, 0, 1, kv)
+        self._inflight_rows = self._S + 1
         self._rows_out(BUF_MSG, 0, self._S + 2, 1)
         self._inflight += 1
-        self._result(None)                         # the late ranks answer every message; this one is discarded
+        self._answer()                             # the late ranks answer every message; this one is discarded
 
     # ------------------------------------------------------------------ whole generation (collective)
     def serve_forever(self) -> int:
@@ -275,24 +373,35 @@ class PipelineSpeculativeDecoder:
             self._agree(None, [], 0, 0)
 
     def generate(self, prompt_ids: Optional[Sequence[int]], eos_token_ids: Sequence[int], max_steps: int,
-                 num_speculations: int, on_step=None) -> Optional[PipelineResult]:
-        """Rank 0 passes the prompt and the settings; other ranks' arguments are ignored.  Mirrors SSG:32-99 (greedy).
+                 num_speculations: int, on_step=None, sampling: Optional[Sampling] = None, driver=None) -> Optional[PipelineResult]:
+        """Rank 0 passes the prompt and the settings; other ranks' arguments are ignored.  Mirrors SSG:32-99.
         on_step (rank 0): called after every speculation step with (draft tokens, number accepted, emitted tokens, next input
         token); a truthy return value ends the generation after that step (stopping criteria, SSG:92-95; streamers hang here too).
+        sampling (rank 0): sample=True -- draws and modified rejection sampling on the devices (module docstring), draw for draw
+        the one-GPU `lsk_spec_generate_sampled` under the same (seed, offset).
+        driver (rank 0): logits processors -- `driver(self)` runs the generation itself on rank 0 (hip_strategies' slow path) and
+        gets every verify's logits rows through `remote_verify`; its return value is this call's.
         Ranks > 0 get an empty result, or None when rank 0 shut the pipeline down instead of starting a generation."""
         if self.rank == 0 and prompt_ids is None:
             raise ValueError("rank 0 must pass the prompt")
-        agreed = self._agree(prompt_ids, eos_token_ids, int(max_steps), int(num_speculations))
+        mode = MODE_LOGITS if driver is not None else (MODE_SAMPLED if sampling is not None else MODE_GREEDY)
+        agreed = self._agree(prompt_ids, eos_token_ids, int(max_steps), int(num_speculations), mode, sampling)
         if agreed is None:
             return None
-        P0, S, max_steps, eos = agreed
-        self._S = S
+        P0, S, max_steps, eos, mode, sampling = agreed
+        self._S, self._mode, self._sampling = S, mode, sampling
         if self.rank > 0:
-            self._serve(P0, S)
+            self._serve(P0, S, mode, sampling)
             return PipelineResult([], None, [])
         self._inflight = 0
+        self._inflight_rows = S + 1
         self._kv_host = 0
         try:
+            if driver is not None:
+                out = driver(self)
+                if self.world > 1:
+                    self._stop(self._kv_host)
+                return out
             return self._drive(prompt_ids, eos, max_steps, S, on_step)
         except BaseException:
             # An error on rank 0 mid-generation (an inconsistent result block, a failed launch) must not leave the other ranks
@@ -301,11 +410,25 @@ class PipelineSpeculativeDecoder:
             if self.world > 1:
                 try:
                     while self._inflight > 0:
-                        self._result(None)
+                        self._answer()
                     self._stop(self._kv_host)
                 except Exception:       # noqa: BLE001
                     pass
             raise
+
+    # ------------------------------------------------------------------ logits mode: rank 0's slow path asks for one verify at a time
+    def remote_verify(self, P: int, m: int) -> torch.Tensor:
+        """Rank 0, inside a `driver`: the late layers + final norm + lm_head of `forward_remainder` (LMU:364-387) over step rows
+        [0, m) and the P - 1 prompt rows in front of them, wherever those layers live -> logits [(P - 1) + m, V] in the model dtype
+        on rank 0's device (the reference returns logits for EVERY input row; processors see them all, SSG:172-173)."""
+        local = self._ship(P, m, self._kv_host, 0)
+        rows = local if local is not None else self._answer()
+        return rows.to(self.be.device)[: P - 1 + m]
+
+    def commit(self, kv: int) -> None:
+        """Rank 0, inside a `driver`: the verified context length after a step (the next header carries it to the other ranks)."""
+        self._kv_host = int(kv)
+        self.be.set_kv_len(self._kv_host)
 
     def _drive(self, prompt_ids, eos, max_steps: int, S: int, on_step=None) -> PipelineResult:
         """Rank 0's loop (SSG:51-95)."""
@@ -319,18 +442,24 @@ class PipelineSpeculativeDecoder:
         # rows of one block: input + S drafts; a continuation lives in rows S+1 .. 2S+1 (+ one row for its own guess)
         room_cont = 2 * S + 2 <= _MAX_ROWS
         room_chain = 2 * S + 3 <= _MAX_ROWS
+        sm = self._sampling if self._mode == MODE_SAMPLED else None
+        step_i = 0                                 # a sampled step draws at Philox offset sm.offset + step_i (lsk_spec_generate_sampled's contract)
         while len(out) < max_steps:
             s_eff = max(0, min(S, max_steps - len(out) - 1))
             P = len(cur)
             t0 = time.perf_counter()
             fresh = not (cont is not None and s_eff == S)
             want_guess = False
-            if fresh:
+            off = sm.offset + step_i if sm is not None else None
+            if fresh and sm is not None:
+                # (no optimistic continuation under sampling: the bonus token is a draw from the LAST rank's distribution)
+                be.draft_block_sampled(cur, 0, s_eff + 1, P - 1, E, False, sm.temperature, sm.top_k, sm.top_p, sm.seed, off)
+            elif fresh:
                 want_guess = self.optimistic and s_eff == S and room_cont
                 be.draft_block(cur, 0, s_eff + 1, P - 1, E, head_last=want_guess)
             # ship the block BEFORE looking at the drafts on the host: the drafted-EOS cut (SSG:146-148) and the prefix match are
             # the acceptance kernel's job on the last rank; the late ranks compute rows the cut drops, harmlessly
-            local = self._ship(P, s_eff + 1, kv, 0)
+            local = self._ship(P, s_eff + 1, kv, 0, off)
             t1 = time.perf_counter()
             if fresh:
                 toks = be.row_tokens(1, s_eff + (1 if want_guess else 0)) if (s_eff or want_guess) else []
@@ -345,7 +474,8 @@ class PipelineSpeculativeDecoder:
                 # step k+1, optimistically: input = the guessed bonus token (its embedding already sits in row S+1)
                 be.draft_block(None, S + 1, S + 1, P - 1 + S + 1, E, head_last=room_chain)
                 self._stats["optimistic_attempts"] += 1
-            res = self._result(local)
+            res = self._result(local, 0, off)
+            step_i += 1
             t2 = time.perf_counter()
             n, td, nxt = res[0], res[1], res[2]
             emitted = res[4:4 + n + 1]

@@ -10,10 +10,16 @@ MI355X-native partition instead: every rank stays, owns a contigu
 * ranks > 0 run `strategy.serve(model)` instead of the reference's `exit()`: they take part in one generation after the
   other (verify blocks over RCCL point-to-point, layerskip_amd/pipeline.py) until rank 0 calls `strategy.shutdown()`.
 
-`HipPipelineSelfSpeculativeGenerationStrategy` decodes greedily (SSG:186-190 on the last rank's acceptance kernel);
-`HipPipelineAutoRegressiveGenerationStrategy` is the same pipeline with zero speculations (one token per round trip:
-ARG:26-80 over a model that does not fit one GPU).  Streamers (both protocols) and stopping criteria are served per step on
-rank 0; `sample=True` and logits processors need full logits rows on rank 0 and are refused with a clear error.
+`HipPipelineSelfSpeculativeGenerationStrategy` covers what the one-GPU strategy covers:
+  greedy   SSG:186-190 on the last rank's acceptance kernel;
+  sampled  `sample=True` (the reference's default, generator_base.py:39): draws and modified rejection sampling (SSG:191-199) on the
+           devices -- rank 0's p_i(x_i) travel in the header, the last rank's q_n comes back with the result
+           (layerskip_amd/pipeline.py); draw for draw the one-GPU engine's generation under the same torch seed;
+  slow     logits processors (`no_repeat_ngram_size`, generator_base.py:77-85): the one-GPU slow path on rank 0 with the verify's
+           logits rows fetched from the last rank.
+`HipPipelineAutoRegressiveGenerationStrategy` is the same pipeline with zero speculations (one token per round trip: ARG:26-80 over
+a model that does not fit one GPU); early-exit-only decoding (ARG:44-51) runs rank-locally on rank 0, which owns those layers.
+Streamers (both protocols) and stopping criteria are served per step on rank 0.
 """
 from __future__ import annotations
 
@@ -25,7 +31,8 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
-from .pipeline import PipelineSpeculativeDecoder, plan_partition
+from .hip_strategies import HipAutoRegressiveGenerationStrategy, HipSelfSpeculativeGenerationStrategy
+from .pipeline import PipelineSpeculativeDecoder, Sampling, plan_partition
 from .strategy_api import GenerationConfig, GenerationStrategy, GenerationStrategyResult
 
 
@@ -85,6 +92,66 @@ def _hip_backend(model, layer_range, **engine_kwargs):
 _DECODERS = weakref.WeakKeyDictionary()
 
 
+class _Rank0SlowStrategy(HipSelfSpeculativeGenerationStrategy):
+    """The one-GPU slow path (logits processors; hip_strategies._slow_step) with the engine and the late layers where the pipeline
+    keeps them: the draft loop runs row by row on rank 0's engine (early layers + its head copy), the verify's logits rows come from
+    the last rank (`PipelineSpeculativeDecoder.remote_verify`), the rollback is rank 0's counter write + the next header."""
+
+    def __init__(self, dec: PipelineSpeculativeDecoder) -> None:
+        super().__init__(fused_generate=False, device_sampling=False)
+        self._dec = dec
+
+    def _get_engine(self, model, check_weights: bool = True):
+        return self._dec.be
+
+    def _verify_logits(self, engine, P: int, td: int, E: int, sbuf: int, sbase: int, prompt_rows: bool) -> torch.Tensor:
+        if sbuf != 0 or sbase != 0:
+            raise ValueError("the layer pipeline verifies at most 16 rows per step (num_speculations <= 15)")
+        rows = self._dec.remote_verify(P, td + 1)                       # [(P - 1) + td + 1, V]
+        return (rows if prompt_rows else rows[P - 1:]).unsqueeze(0)
+
+    def _commit(self, engine, kv_len: int) -> None:
+        self._dec.commit(kv_len)
+
+
+class _Rank0SlowARStrategy(HipAutoRegressiveGenerationStrategy):
+    """The one-GPU autoregressive slow path (logits processors / sample=True: logits rows + torch on the host) over the pipeline:
+    rank 0's layers locally, the rest and the head through `remote_verify` (one row per round trip)."""
+
+    def __init__(self, dec: PipelineSpeculativeDecoder) -> None:
+        super().__init__(fused_generate=False)
+        self._dec = dec
+
+    def _get_engine(self, model):
+        return self._dec.be
+
+    def _forward_logits(self, engine, ids: List[int], layer_end: int, prompt_rows: bool) -> torch.Tensor:
+        from .engine import BUF_BULK, BUF_STEP
+        P, first = len(ids), self._dec.E            # rank 0 owns [0, first); the pipeline's `exit layer` of an AR run is that boundary
+        if P > 1:
+            engine.embed_rows(ids[:-1], BUF_BULK, 0)
+            engine.run_bulk(P - 1, 0, first)
+        engine.embed_rows(ids[-1:], BUF_STEP, 0)
+        engine.run_layers(BUF_STEP, 0, 1, P - 1, 0, first)
+        rows = self._dec.remote_verify(P, 1)
+        return (rows if prompt_rows else rows[P - 1:]).unsqueeze(0)
+
+    def _commit(self, engine, kv_len: int) -> None:
+        self._dec.commit(kv_len)
+
+
+class _Rank0LocalARStrategy(HipAutoRegressiveGenerationStrategy):
+    """Early-exit-only autoregressive decoding (ARG:44-51) on a pipeline: layers [0, exit_layer) and a head copy are rank 0's, so the
+    whole generation is rank-local -- the one-GPU strategy on rank 0's engine, no message moves."""
+
+    def __init__(self, dec: PipelineSpeculativeDecoder) -> None:
+        super().__init__()
+        self._dec = dec
+
+    def _get_engine(self, model):
+        return self._dec.be
+
+
 class HipPipelineSelfSpeculativeGenerationStrategy(GenerationStrategy):
     """`SelfSpeculativeGenerationStrategy` (SSG:31-99) over N GPUs.  All ranks construct it with the same `partition`;
     rank 0 calls `generate_token_ids`, the others `serve(model)`."""
@@ -135,6 +202,9 @@ class HipPipelineSelfSpeculativeGenerationStrategy(GenerationStrategy):
     def _speculations(self, cfg: GenerationConfig) -> int:
         return max(0, int(cfg.num_speculations))
 
+    def _slow_strategy(self, dec: PipelineSpeculativeDecoder):
+        return _Rank0SlowStrategy(dec)
+
     def _exit_layer(self, cfg: GenerationConfig, num_layers: int) -> int:
         e = int(cfg.exit_layer)
         first = self.partition[0][1]
@@ -146,15 +216,31 @@ class HipPipelineSelfSpeculativeGenerationStrategy(GenerationStrategy):
                            logits_processors=None, stopping_criteria=None, streamer=None) -> GenerationStrategyResult:
         if self.ctx.rank != 0:
             raise RuntimeError("generate_token_ids is rank 0's call; ranks > 0 run strategy.serve(model)")
-        # refused BEFORE any collective, so the other ranks stay in their serve loop
-        if generation_config.sample:
-            raise NotImplementedError("the layer pipeline decodes greedily (the acceptance kernel runs on the last rank): pass "
-                                      "--sample False, or decode sample=True on one GPU")
-        if logits_processors:
-            raise NotImplementedError("logits processors need full logits rows on rank 0; the layer pipeline keeps them on the last rank")
         dec = self._decoder(model)
         dec.E = self._exit_layer(generation_config, model.config.num_hidden_layers)
         eos = [t for t in eos_token_ids if t is not None]
+        S = self._speculations(generation_config)
+        if logits_processors:
+            # the slow path: every decision on rank 0, on logits rows the user's callables have seen (SSG:138-139, :172-173)
+            inner = self._slow_strategy(dec)
+            cfg = generation_config
+
+            def driver(_dec):
+                return inner.generate_token_ids(model, input_ids, eos, cfg, logits_processors, stopping_criteria, streamer)
+
+            return dec.generate([int(t) for t in input_ids], eos, int(cfg.max_steps), S, driver=driver)
+        sampling = None
+        if generation_config.sample and not self.speculative:
+            # sampled autoregressive decoding: one logits row per round trip, drawn with torch on rank 0 (the one-GPU strategy's path)
+            inner, cfg = self._slow_strategy(dec), generation_config
+            return dec.generate([int(t) for t in input_ids], eos, int(cfg.max_steps), S,
+                                driver=lambda _dec: inner.generate_token_ids(model, input_ids, eos, cfg, logits_processors,
+                                                                             stopping_criteria, streamer))
+        if generation_config.sample:
+            # the seeding contract of the one-GPU strategy (hip_strategies): key = torch.initial_seed(), counter base = one 62-bit draw
+            # from torch's global generator per generation -- torch.manual_seed(s) reproduces a generation, on one GPU or on N
+            sampling = Sampling(float(generation_config.temperature), int(generation_config.top_k), float(generation_config.top_p),
+                                int(torch.initial_seed()), int(torch.randint(0, 2 ** 62, (1,)).item()))
 
         def on_step(drafts, n, emitted, nxt):
             if streamer is not None:
@@ -170,8 +256,8 @@ class HipPipelineSelfSpeculativeGenerationStrategy(GenerationStrategy):
                 return bool(torch.all(stopping_criteria(torch.tensor([[nxt]]), scores=None)))      # SSG:92-95: on the next input
             return False
 
-        res = dec.generate([int(t) for t in input_ids], eos, int(generation_config.max_steps), self._speculations(generation_config),
-                           on_step=on_step if (streamer is not None or stopping_criteria) else None)
+        res = dec.generate([int(t) for t in input_ids], eos, int(generation_config.max_steps), S,
+                           on_step=on_step if (streamer is not None or stopping_criteria) else None, sampling=sampling)
         self.last_steps = list(res.steps)
         return self._result(res)
 
@@ -183,17 +269,30 @@ class HipPipelineSelfSpeculativeGenerationStrategy(GenerationStrategy):
 
 class HipPipelineAutoRegressiveGenerationStrategy(HipPipelineSelfSpeculativeGenerationStrategy):
     """`AutoRegressiveGenerationStrategy` (ARG:25-80) over N GPUs: the same pipeline with zero speculations -- every round trip
-    carries one row and yields one token.  Early-exit-only decoding (`exit_layer > 0`, ARG:44-51) is a one-GPU feature."""
+    carries one row and yields one token.  Early-exit-only decoding (`exit_layer > 0`, ARG:44-51) never leaves rank 0."""
 
     speculative = False
 
     def _speculations(self, cfg: GenerationConfig) -> int:
         return 0
 
+    def _slow_strategy(self, dec: PipelineSpeculativeDecoder):
+        return _Rank0SlowARStrategy(dec)
+
     def _exit_layer(self, cfg: GenerationConfig, num_layers: int) -> int:
-        if int(cfg.exit_layer) > 0 and int(cfg.exit_layer) != num_layers:
-            raise NotImplementedError("early-exit-only autoregressive decoding runs on one GPU (the early layers are rank 0's)")
         return self.partition[0][1]
+
+    def generate_token_ids(self, model, input_ids: List[int], eos_token_ids: List[int], generation_config: GenerationConfig,
+                           logits_processors=None, stopping_criteria=None, streamer=None) -> GenerationStrategyResult:
+        e, L = int(generation_config.exit_layer), model.config.num_hidden_layers
+        if 0 < e < L:
+            if self.ctx.rank != 0:
+                raise RuntimeError("generate_token_ids is rank 0's call; ranks > 0 run strategy.serve(model)")
+            if e > self.partition[0][1]:
+                raise ValueError(f"exit_layer={e}: early-exit-only decoding runs on rank 0, which owns layers [0, {self.partition[0][1]})")
+            return _Rank0LocalARStrategy(self._decoder(model)).generate_token_ids(model, input_ids, eos_token_ids, generation_config,
+                                                                                 logits_processors, stopping_criteria, streamer)
+        return super().generate_token_ids(model, input_ids, eos_token_ids, generation_config, logits_processors, stopping_criteria, streamer)
 
     def _result(self, res) -> GenerationStrategyResult:
         return GenerationStrategyResult(predicted_tokens=res.predicted_tokens, acceptance_rate=None)

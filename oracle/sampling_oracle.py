@@ -248,9 +248,10 @@ def device_sample_row(logits: np.ndarray, temperature: float, top_k: int, top_p:
     return int(np.argmax(score)), probs
 
 
-def device_accept(draft_tokens: Sequence[int], verified_tokens: Sequence[int], p_draft: Sequence[np.ndarray],
-                  p_verify: Sequence[np.ndarray], eos: Sequence[int], seed: int, offset: int) -> Tuple[int, int, int]:
-    """(num_matches, num_drafts, emitted token) as lsk_accept_sampled_kernel decides them."""
+def device_accept_test(draft_tokens: Sequence[int], p_draft_of_token: Sequence[float], p_verify: Sequence[np.ndarray], eos: Sequence[int],
+                       seed: int, offset: int) -> Tuple[int, int]:
+    """(num_matches, num_drafts): the acceptance TEST of lsk_accept_sampled_kernel / lsk_pipeline_accept_sampled_kernel.  It needs only
+    the scalars p_i(x_i) of the draft distributions -- what the layer pipeline's header carries to the last rank."""
     td = len(draft_tokens)
     for i, t in enumerate(draft_tokens):
         if t in eos:
@@ -260,14 +261,28 @@ def device_accept(draft_tokens: Sequence[int], verified_tokens: Sequence[int], p
     n = 0
     for i in range(td):
         tok = draft_tokens[i]
-        if u[i] < min(np.float32(1.0), np.float32(p_verify[i][tok]) / np.float32(p_draft[i][tok])):
+        if u[i] < min(np.float32(1.0), np.float32(p_verify[i][tok]) / np.float32(p_draft_of_token[i])):
             n += 1
         else:
             break
-    if n == td:
-        return n, td, int(verified_tokens[td])
-    w = p_verify[n].astype(np.float32) - p_draft[n].astype(np.float32)
+    return n, td
+
+
+def device_residual(q_row: np.ndarray, p_row: np.ndarray, fallback: int, seed: int, offset: int) -> int:
+    """The Gumbel-max draw from max(q - p, 0) (lsk_residual_draw): what rank 0 of the layer pipeline does with the q_n it receives."""
+    w = q_row.astype(np.float32) - p_row.astype(np.float32)
+    if not (w > 0).any():
+        return int(fallback)
     uu = device_uniforms(w.shape[0], TAG_RESIDUAL, seed, offset)
     with np.errstate(divide="ignore", invalid="ignore"):
         score = np.where(w > 0, np.log(np.where(w > 0, w, 1.0).astype(np.float64)) - np.log(-np.log(uu.astype(np.float64))), -np.inf)
-    return n, td, int(np.argmax(score))
+    return int(np.argmax(score))
+
+
+def device_accept(draft_tokens: Sequence[int], verified_tokens: Sequence[int], p_draft: Sequence[np.ndarray],
+                  p_verify: Sequence[np.ndarray], eos: Sequence[int], seed: int, offset: int) -> Tuple[int, int, int]:
+    """(num_matches, num_drafts, emitted token) as lsk_accept_sampled_kernel decides them."""
+    n, td = device_accept_test(draft_tokens, [p_draft[i][t] for i, t in enumerate(draft_tokens)], p_verify, eos, seed, offset)
+    if n == td:
+        return n, td, int(verified_tokens[td])
+    return n, td, device_residual(p_verify[n], p_draft[n], draft_tokens[n], seed, offset)

@@ -9,6 +9,11 @@ import torch.nn.functional as F
 from oracle import llama_oracle as lo
 
 
+def _i32(v: int) -> int:
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
 class CpuStageBackend:
     def __init__(self, model, layer_range=None, max_rows=4096):
         self.om = lo.OracleModel.from_hf(model, dtype=torch.float32) if layer_range is None else None
@@ -23,6 +28,8 @@ class CpuStageBackend:
         # 0: step rows, 1: prompt rows, 2: the pipeline message (row 0 = header words, rows 1.. = the verify block)
         self.buf = {0: torch.zeros(16, self.hidden), 1: torch.zeros(max_rows, self.hidden), 2: torch.zeros(17, self.hidden)}
         self._eos = []
+        self.dtype = torch.float32
+        self._p_draft = [None] * 16          # the sampling scratch's p_draft rows (sample=True on the pipeline)
         self.kv = [None] * self.num_layers
         self._kv_len = 0
         self._row_tokens = [0] * 18
@@ -163,6 +170,95 @@ class CpuStageBackend:
 
     def row_tokens(self, row0, n):
         return list(self._row_tokens[row0:row0 + n])
+
+    # ---- sample=True on the pipeline: the oracle's model of lsk_draft_block_sampled / lsk_pipeline_pack_sampled / _tail_sampled /
+    #      lsk_pipeline_residual (csrc/lsk_sample.h), same Philox stream
+    def _logits_np(self, buffer, row_base, m):
+        out = torch.zeros(m, self.vocab)
+        self.run_head(buffer, row_base, m, logits=out, want_tokens=False)
+        return out.to(torch.bfloat16).float().numpy()          # the engine's logits are rounded to the model dtype
+
+    def logits_rows(self, blocks):
+        rows = []
+        for buf, base, count in blocks:
+            for r0 in range(0, count, 16):
+                m = min(16, count - r0)
+                out = torch.zeros(m, self.vocab)
+                self.run_head(buf, base + r0, m, logits=out, want_tokens=False)
+                rows.append(out)
+        return torch.cat(rows)          # fp32, as this backend's run_head hands logits to hip_strategies._logits_rows
+
+    def pipeline_result_words(self):
+        return 64 + self.vocab
+
+    def draft_block_sampled(self, input_ids, row0, n_rows, pos_off0, exit_layer, head_last, temperature, top_k, top_p, seed, offset):
+        from oracle import sampling_oracle as so
+        E = int(exit_layer)
+        if input_ids is not None:
+            ids = list(input_ids)
+            P = len(ids)
+            assert row0 == 0 and pos_off0 == P - 1
+            if P > 1:
+                self.embed_rows(ids[:-1], 1, 0)
+                self.run_bulk(P - 1, 0, E)
+            self._row_tokens[0] = ids[-1]
+            self.embed_rows(ids[-1:], 0, 0)
+        for j in range(n_rows):
+            self.run_layers(0, row0 + j, 1, pos_off0 + j, 0, E)
+            if j + 1 < n_rows or head_last:
+                tok, probs = so.device_sample_row(self._logits_np(0, row0 + j, 1)[0], temperature, top_k, top_p, seed, offset, j)
+                self._p_draft[row0 + j] = probs
+                self._row_tokens[row0 + j + 1] = tok
+                self.embed_rows([tok], 0, row0 + j + 1)
+
+    def pipeline_pack_sampled(self, go, prompt_len, src_row, m, kv, offset):
+        import numpy as np
+        self.pipeline_pack(go, prompt_len, src_row, m, kv)
+        hdr = self._hdr()
+        hdr[24:40] = 0
+        hdr[21], hdr[22], hdr[23] = 1, _i32(offset & 0xFFFFFFFF), _i32(offset >> 32)
+        if go:
+            for i in range(m - 1):
+                pd = np.float32(self._p_draft[src_row + i][self._row_tokens[src_row + 1 + i]])
+                hdr[24 + i] = int(np.array([pd], dtype=np.float32).view(np.int32)[0])
+
+    def pipeline_tail_sampled(self, m, temperature, top_k, top_p, seed, offset):
+        import numpy as np
+        from oracle import sampling_oracle as so
+        hdr = [int(v) for v in self._hdr()[:40].tolist()]
+        rows = min(max(hdr[3], 1), 16)
+        vl = self._logits_np(2, 1, m)
+        verified, p_verify = [], []
+        for r in range(m):
+            tok, probs = so.device_sample_row(vl[r], temperature, top_k, top_p, seed, offset, so.TAG_VERIFY + r)
+            verified.append(tok)
+            p_verify.append(probs)
+        drafts = hdr[5:5 + rows - 1]
+        pd = np.array(hdr[24:24 + rows - 1], dtype=np.int32).view(np.float32)
+        n, td = so.device_accept_test(drafts, pd, p_verify, self._eos, seed, offset)
+        self._kv_len += hdr[2] + n
+        res = torch.zeros(64 + self.vocab, dtype=torch.int32)
+        nxt = verified[td] if n == td else -1
+        res[0], res[1], res[2], res[3] = n, td, nxt, self._kv_len
+        for i in range(n):
+            res[4 + i] = drafts[i]
+        res[4 + n] = nxt
+        res[21] = 1 if n < td else 0
+        res[22] = 0 if (hdr[21] == 1 and hdr[22] == _i32(offset & 0xFFFFFFFF) and hdr[23] == _i32(offset >> 32)) else 1
+        res[64:] = torch.from_numpy(p_verify[n].astype(np.float32).view(np.int32).copy())
+        return res
+
+    def pipeline_residual(self, block, src_row, seed, offset):
+        import numpy as np
+        from oracle import sampling_oracle as so
+        if not int(block[21]):
+            return
+        n = int(block[0])
+        q = block[64:].numpy().view(np.float32)
+        tok = so.device_residual(q, self._p_draft[src_row + n], self._row_tokens[src_row + 1 + n], seed, offset)
+        block[2] = tok
+        block[4 + n] = tok
+        block[21] = 0
 
     def shift_rows(self, src, dst, n):
         nr = min(n, 16 - src)

@@ -65,7 +65,7 @@ class FullFakeEngine:
     entry points, built FROM those blocks: the complete HipEngine surface the strategies touch, on the CPU oracle
     (fp32).  Lets the plugin run under the reference's own HuggingfaceLlamaGenerator without a GPU."""
 
-    def __new__(cls, model):
+    def __new__(cls, model, layer_range=None):
         from cpu_stage_backend import CpuStageBackend
 
         class _Impl(CpuStageBackend):
@@ -113,4 +113,4 @@ class FullFakeEngine:
                 self.set_kv_len(self.kv_len + P)
                 return tok
 
-        return _Impl(model)
+        return _Impl(model, layer_range=layer_range)

@@ -94,6 +94,25 @@ def test_benchmark_main_on_a_real_checkpoint_one_process_and_torchrun_style(gpu_
     assert set(multi) == {"acceptance_rate", "total_time", "time_per_token", "tokens_per_second"}
 
 
+@pytest.mark.parametrize("flags", [["--sample", "True", "--temperature", "0.7", "--top_k", "50", "--top_p", "0.95"],
+                                   ["--sample", "False", "--no_repeat_ngram_size", "2"],
+                                   ["--sample", "True", "--no_repeat_ngram_size", "3", "--top_k", "0"]])
+def test_the_reference_readme_flags_run_on_the_pipeline(gpu_device, ckpt, monkeypatch, tmp_path, flags):
+    """The reference's README command lines pass `--sample True` (its default, generator_base.py:39) and benchmark.py's
+    no_repeat_ngram_size (generator_base.py:77-85): on the layer pipeline they give the one-process engine's tokens -- draw for draw
+    under the same --seed (sampled acceptance split over the ranks), logits processors on rank 0 with the last rank's logits rows."""
+    argv = ["--model", ckpt["path"], "--dataset", "custom_jsonl", "--data_path", ckpt["data"], "--num_samples", "3", "--random_shuffle", "False",
+            "--generation_strategy", "self_speculative", "--output_dir", str(tmp_path), "--seed", "7"] + [a for a in COMMON if a not in ("--sample", "False")] + flags
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    benchmark = _load_driver("benchmark", monkeypatch)
+    single = benchmark.main(argv)
+    single_ids = benchmark.benchmark.last_outputs
+    assert len(single_ids) == 3 and all(len(t) == 24 for t in single_ids)
+    multi, multi_ids = _launch(2, "benchmark", argv)
+    assert multi_ids == single_ids
+    assert multi["acceptance_rate"]["mean"] == pytest.approx(single["acceptance_rate"]["mean"], abs=1e-12)
+
+
 def test_correctness_main_torchrun_style_and_generate_repl_on_the_engine(gpu_device, ckpt, monkeypatch, capsys, tmp_path):
     argv = ["--model", ckpt["path"], "--dataset", "custom_jsonl", "--data_path", ckpt["data"], "--num_samples", "2", "--output_dir", str(tmp_path)] + COMMON
     code, _ = _launch(2, "correctness", argv)

@@ -73,6 +73,71 @@ def test_pipeline_of_hip_engines_equals_the_fused_engine(gpu_device, world, over
         assert stats["optimistic_attempts"] > stats["optimistic_hits"]
 
 
+SAMPLING = dict(temperature=0.8, top_k=50, top_p=0.9, seed=20240917, offset=(1 << 45) + 3)
+
+
+def _sampled_worker(rank, world, port, queue, shape, E, S, max_steps, top_k):
+    """sample=True on the pipeline (the reference's default, generator_base.py:39): rank 0 drafts with draws, the last rank runs the
+    acceptance test on the header's p_i(x_i) and returns q_n, rank 0 draws the residual token."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from layerskip_amd import synthetic
+        from layerskip_amd.engine import HipEngine
+        from layerskip_amd.pipeline import PipelineSpeculativeDecoder, Sampling, plan_partition
+        dev = torch.device("cuda:0")
+        cfg = synthetic.make_config(shape)
+        part = plan_partition(cfg.num_hidden_layers, E, world)
+        model = synthetic.build_model(cfg, seed=2, exit_layer=E, late_damping=0.2, dtype=torch.bfloat16, device=dev, gen_device="cpu", layer_range=part[rank])
+        eng = HipEngine(model, max_ctx=512, max_prompt=64, layer_range=part[rank])
+        dec = PipelineSpeculativeDecoder(eng, rank, world, part, E, comm_device=torch.device("cpu"))
+        prompt = synthetic.make_prompt(cfg.vocab_size, 23, 5)
+        sm = dict(SAMPLING, top_k=top_k)
+        res = dec.generate(prompt if rank == 0 else None, [cfg.vocab_size], max_steps, S, sampling=Sampling(**sm) if rank == 0 else None)
+        if rank == 0:
+            queue.put((res.predicted_tokens, res.steps))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,E,S,top_k", [(2, "tiny-gqa", 3, 6, 50), (3, "tiny-gqa", 3, 6, 0), (2, "slice-1B", 2, 4, 0), (2, "slice-1B", 2, 4, 40)])
+def test_sampled_pipeline_of_hip_engines_is_draw_for_draw_the_fused_engine(gpu_device, world, shape, E, S, top_k):
+    """Same (seed, offset) -> the SAME tokens and per-step (drafts, matches) as lsk_spec_generate_sampled on one engine: the split
+    acceptance (scalars forward, one probability row back) makes the same draws and comparisons as lsk_accept_sampled_kernel.
+    slice-1B: V = 128 256, the multi-workgroup histogram form of the draw (csrc/lsk_sample.h), with and without top-k."""
+    from layerskip_amd import synthetic
+    from layerskip_amd.engine import HipEngine
+    max_steps = 40
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_sampled_worker, args=(r, world, port, queue, shape, E, S, max_steps, top_k)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tokens, steps = queue.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = synthetic.make_config(shape)
+    model = synthetic.build_model(cfg, seed=2, exit_layer=E, late_damping=0.2, dtype=torch.bfloat16, device=gpu_device, gen_device="cpu")
+    eng = HipEngine(model, max_ctx=512, max_prompt=64)
+    prompt = synthetic.make_prompt(cfg.vocab_size, 23, 5)
+    sm = dict(SAMPLING, top_k=top_k)
+    want, matches, drafts, want_steps = eng.spec_generate_sampled(prompt, S, E, [cfg.vocab_size], max_steps, sm["temperature"], sm["top_k"],
+                                                                  sm["top_p"], sm["seed"], sm["offset"])
+    eng.close()
+    assert tokens == want
+    assert [tuple(s) for s in steps] == [tuple(s) for s in want_steps]
+    assert any(n < td for td, n in want_steps) and any(n == td and td > 0 for td, n in want_steps)   # rejections AND full acceptances occurred
+
+
 def _nccl_worker(rank, world, port, queue):
     """One rank per DEVICE, backend nccl (= RCCL): rows go straight from / into the engines' message buffers over xGMI."""
     import sys
