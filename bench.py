@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 from layerskip_amd import GenerationConfig, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline figure is never used)
 
 
 def parse_args():
@@ -73,7 +74,7 @@ def parse_args():
                          "generator (seconds; a different checkpoint of the same distribution)")
     ap.add_argument("--no-reference-parity", action="store_true", help="skip the leg that compares the engine with the reference fixture")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the llama3-8B / llama3.2-1B legs (BASELINE configs #3 and #1's shape)")
-    ap.add_argument("--other-configs", default="llama3-8B,llama3.2-1B")
+    ap.add_argument("--other-configs", default="llama3-8B,llama3.2-1B,llama2-13B")
     ap.add_argument("--graph-steps", action="store_true",
                     help="replay steady-state speculation steps from hipGraphs (LSK_OPT_GRAPH_STEPS; default off, DESIGN.md 3.3)")
     return ap.parse_args()
@@ -341,6 +342,10 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         out["path_roofline"] = {"algorithmic_bytes_per_generation": total_b // max(1, len(step_traces)),
                                 "floor_tokens_per_s_at_8TBs": round(produced / floor_s, 1),
                                 "frac_of_floor": round((value / world) / (produced / floor_s), 4)}
+    if world == 1:
+        out["prefill"] = prefill_leg(args, cfg, engine)
+    if spec and world == 1:
+        out["autoregressive"] = autoregressive_leg(args, cfg, model, eos, value)
     if spec and world == 1 and cpu_weights and not args.no_reference_parity:
         ref = reference_parity(args, cfg, model, E, S)
         if ref is not None:
@@ -360,6 +365,66 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         torch.cuda.empty_cache()
         out["other_configs"] = other_configs(args, dev)
     return out
+
+
+def prefill_leg(args, cfg, engine):
+    """The one MFMA-shaped part of the path: the prompt rows through every layer (forward_early + forward_remainder over the prompt,
+    llama_model_utils.py:252, :375-383) on the MFMA-tiled prefill kernels -- best of 5 of `lsk_run_bulk(prompt_len - 1 rows, all layers)`
+    between two device synchronisations, against the dense bf16 MFMA peak (north_star: "MFMA utilisation against gfx950 peak")."""
+    from layerskip_amd.engine import BUF_BULK
+    rows = args.prompt_len - 1
+    H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    hd = getattr(cfg, "head_dim", None) or H // cfg.num_attention_heads
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    proj_params = 2 * H * nh * hd + 2 * H * nkv * hd + 3 * H * I
+    flops = 2.0 * rows * proj_params * L + 4.0 * nh * hd * (rows * (rows + 1) / 2) * L      # projections + causal QK^T and PV
+    prompt = synthetic.make_prompt(cfg.vocab_size, args.prompt_len, 0)
+    best = 1e9
+    for _ in range(5):
+        engine.reset()
+        engine.embed_rows(prompt[:rows], BUF_BULK, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        engine.run_bulk(rows, 0, engine.num_layers)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    engine.reset()
+    tflops = flops / best / 1e12
+    fetch = None
+    pmc = os.path.join(ROOT, "profiles", "r05_prefill_fetch.json")
+    if args.model == "llama2-7B" and os.path.exists(pmc):
+        fetch = json.load(open(pmc))
+    return {"rows": rows, "ms": round(1e3 * best, 3), "tflops": round(tflops, 1), "peak_tflops": MFMA_PEAK_TFLOPS,
+            "frac_of_mfma_peak": round(tflops / MFMA_PEAK_TFLOPS, 4), "flops": int(flops),
+            "fetch_over_weights": fetch,
+            "note": "best of 5; host clock around one lsk_run_bulk call over all layers (projections on lsk_gemm_big_kernel, "
+                    "attention on lsk_attn_prefill_kernel); 1.4 % of a 512/512 generation"}
+
+
+def autoregressive_leg(args, cfg, model, eos, spec_value):
+    """The engine's OWN autoregressive decoding of the same prompt and length (reference autoregressive_generator.py:26-80, the paper's
+    baseline): the quantity self-speculation is measured against -- speculative_speedup = spec tokens/s / AR tokens/s."""
+    from layerskip_amd.hip_strategies import HipAutoRegressiveGenerationStrategy
+    strat = HipAutoRegressiveGenerationStrategy()
+    gen = GenerationConfig(max_steps=args.max_steps, exit_layer=-1, num_speculations=-1, sample=False, generation_strategy="autoregressive")
+    strat.generate_token_ids(model, synthetic.make_prompt(cfg.vocab_size, args.prompt_len, 999), eos,
+                             GenerationConfig(max_steps=32, exit_layer=-1, num_speculations=-1, sample=False, generation_strategy="autoregressive"))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = strat.generate_token_ids(model, synthetic.make_prompt(cfg.vocab_size, args.prompt_len, 0), eos, gen)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tps = len(res.predicted_tokens) / dt
+    H, I, V, L = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers
+    hd = getattr(cfg, "head_dim", None) or H // cfg.num_attention_heads
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    w_all = L * 2 * (2 * H * nh * hd + 2 * H * nkv * hd + 3 * H * I + 2 * H) + 2 * V * H
+    n = len(res.predicted_tokens)
+    total_b = sum(w_all + L * 2 * nkv * hd * 2 * (args.prompt_len + i) for i in range(n))
+    floor_tps = n / (total_b / (HBM_PEAK_GBS * 1e9))
+    return {"value": round(tps, 2), "unit": "tokens/s", "new_tokens": n, "floor_tokens_per_s_at_8TBs": round(floor_tps, 1),
+            "frac_of_floor": round(tps / floor_tps, 4), "speculative_speedup": round(spec_value / tps, 3),
+            "sample": "1 warm-up (32 tokens) + 1 timed generation of prompt 0, lsk_ar_generate"}
 
 
 def other_configs(args, dev):

@@ -88,6 +88,113 @@ struct AttnCombineParams {
     int ldo;
 };
 
+// ---- wide forms of the two merges (rows x features beyond one trip of the 256 threads in the narrow forms): W adjacent features per work
+// item, W = 4 while that is one trip (a 7-row verify pass), W = 8 beyond (9 .. 16 rows: llama2-13B's 9-row and llama2-70B's 13-row
+// verify passes took TWO trips of each loop at W = 4 -- the combine's second trip alone was a third page round trip of this latency-bound
+// kernel).  Every element keeps its own sum -- wave order in the wave merge, page order in the combine -- whatever W: bit-identical rows.
+template <int HD, int W, bool FUSED>
+__device__ __forceinline__ void lsk_attn_merge_wide(const float* __restrict__ sm, float* __restrict__ part, int n_rows, int M, int inv_m, int head0,
+                                                    int max_pages, int page_l, int tid) {
+    constexpr int PSTRIDE = HD + 2;
+    constexpr int LS = HD + 4;
+    constexpr int IPR = HD / W + 1;                              // items per row: HD / W feature groups + the (max, sum) pair
+    for (int e = tid; e < n_rows * IPR; e += LSK_ATTN_THREADS) {
+        const int i = e / IPR;
+        const int q = e - i * IPR;
+        float f[LSK_ATTN_WAVES];
+        float m = LSK_ATTN_NEG;
+#pragma unroll
+        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) { f[ww] = sm[(ww * 16 + i) * LS + HD]; m = fmaxf(m, f[ww]); }
+#pragma unroll
+        for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) f[ww] = __builtin_amdgcn_exp2f(f[ww] - m);
+        const int ih = (i * inv_m) >> 8;
+        float* rowp = part + (((size_t)(head0 + ih) * max_pages + page_l) * LSK_ROWS + (i - ih * M)) * PSTRIDE;
+        const int d = (q < HD / W) ? q * W : HD;
+        float v[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[j] = 0.f;
+        if (q < HD / W) {
+#pragma unroll
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
+#pragma unroll
+                for (int k = 0; k < W / 4; ++k) {
+                    const f32x4 a = *(const f32x4*)(sm + (ww * 16 + i) * LS + d + 4 * k);        // 16-byte aligned: LS and d are multiples of 4
+                    v[4 * k + 0] += a[0] * f[ww]; v[4 * k + 1] += a[1] * f[ww]; v[4 * k + 2] += a[2] * f[ww]; v[4 * k + 3] += a[3] * f[ww];
+                }
+            }
+        } else {
+            v[0] = m;
+#pragma unroll
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) v[1] += sm[(ww * 16 + i) * LS + HD + 1] * f[ww];   // the running sum l
+        }
+        unsigned long long* dstp = (unsigned long long*)(rowp + d);
+#pragma unroll
+        for (int k = 0; k < W / 2; ++k) {
+            if (k == 0 || q < HD / W) {
+                const unsigned long long pr = (unsigned long long)__builtin_bit_cast(unsigned, v[2 * k]) | ((unsigned long long)__builtin_bit_cast(unsigned, v[2 * k + 1]) << 32);
+                if (FUSED) __hip_atomic_store(dstp + k, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+                else dstp[k] = pr;
+            }
+        }
+    }
+}
+
+template <int HD, int W>
+__device__ __forceinline__ void lsk_attn_combine_wide(const float* __restrict__ part, elem_t* __restrict__ out, int ldo, int n_rows, int M, int inv_m,
+                                                      int head0, int max_pages, int base_pos, int tid) {
+    constexpr int PSTRIDE = HD + 2;
+    for (int e = tid; e < n_rows * (HD / W); e += LSK_ATTN_THREADS) {
+        const int i = e / (HD / W);
+        const int d = (e - i * (HD / W)) * W;
+        const int ih = (i * inv_m) >> 8;
+        const int r = i - ih * M;
+        const int head = head0 + ih;
+        const float* base = part + ((size_t)head * max_pages) * LSK_ROWS * PSTRIDE;
+        const int n_pages = (base_pos + r) / LSK_ATTN_PAGE + 1;
+        float m = LSK_ATTN_NEG, l = 0.f;
+        float a[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) a[j] = 0.f;
+        for (int p0 = 0; p0 < n_pages; p0 += 8) {
+            float mo[8], lo[8], x[W][8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int pg = min(p0 + k, n_pages - 1);
+                const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
+                // (max, sum) and the features are 8-byte aligned pairs (row stride (HD + 2) * 4 B, d even): 64-bit sc1 loads
+                const unsigned long long ml = __hip_atomic_load((const unsigned long long*)(src + HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mo[k] = __builtin_bit_cast(float, (unsigned)ml);
+                lo[k] = __builtin_bit_cast(float, (unsigned)(ml >> 32));
+#pragma unroll
+                for (int j = 0; j < W / 2; ++j) {
+                    const unsigned long long xx = __hip_atomic_load((const unsigned long long*)(src + d + 2 * j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x[2 * j][k] = __builtin_bit_cast(float, (unsigned)xx);
+                    x[2 * j + 1][k] = __builtin_bit_cast(float, (unsigned)(xx >> 32));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p0 + k < n_pages) {
+                    const float mn = fmaxf(m, mo[k]);
+                    const float fa = __builtin_amdgcn_exp2f(m - mn);
+                    const float fb = __builtin_amdgcn_exp2f(mo[k] - mn);
+                    l = l * fa + lo[k] * fb;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) a[j] = a[j] * fa + x[j][k] * fb;
+                    m = mn;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < W / 4; ++j) {
+            const elem_t o0 = f2e(a[4 * j] / l), o1 = f2e(a[4 * j + 1] / l), o2 = f2e(a[4 * j + 2] / l), o3 = f2e(a[4 * j + 3] / l);
+            const unsigned long long packed = (unsigned long long)__builtin_bit_cast(unsigned short, o0) | ((unsigned long long)__builtin_bit_cast(unsigned short, o1) << 16) |
+                                              ((unsigned long long)__builtin_bit_cast(unsigned short, o2) << 32) | ((unsigned long long)__builtin_bit_cast(unsigned short, o3) << 48);
+            *(unsigned long long*)(out + (size_t)r * ldo + head * HD + d + 4 * j) = packed;
+        }
+    }
+}
+
 template <int HD, bool FUSED>
 __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplitParams& p, const int col, const int page_l, unsigned char* lds) {
     constexpr int KS = HD / 32;              // k-steps of QK^T
@@ -244,43 +351,10 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
             if (fused) __hip_atomic_store(dstp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
             else *dstp = v;
         }
+    } else if (n_rows * (HD / 4 + 1) <= LSK_ATTN_THREADS) {
+        lsk_attn_merge_wide<HD, 4, FUSED>(sm, p.part, n_rows, M, inv_m, head0, p.max_pages, page_l, tid);
     } else {
-        constexpr int QPR = HD / 4 + 1;                              // items per row: HD / 4 feature quads + the (max, sum) pair
-        for (int e = tid; e < n_rows * QPR; e += LSK_ATTN_THREADS) {
-            const int i = e / QPR;
-            const int q = e - i * QPR;
-            float f[LSK_ATTN_WAVES];
-            float m = LSK_ATTN_NEG;
-#pragma unroll
-            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) { f[ww] = sm[(ww * 16 + i) * LS + HD]; m = fmaxf(m, f[ww]); }
-#pragma unroll
-            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) f[ww] = __builtin_amdgcn_exp2f(f[ww] - m);
-            const int ih = (i * inv_m) >> 8;
-            float* rowp = p.part + (((size_t)(head0 + ih) * p.max_pages + page_l) * LSK_ROWS + (i - ih * M)) * PSTRIDE;
-            const int d = (q < HD / 4) ? q * 4 : HD;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (q < HD / 4) {
-#pragma unroll
-                for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
-                    const f32x4 a = *(const f32x4*)(sm + (ww * 16 + i) * LS + d);        // 16-byte aligned: LS and d are multiples of 4
-                    v[0] += a[0] * f[ww]; v[1] += a[1] * f[ww]; v[2] += a[2] * f[ww]; v[3] += a[3] * f[ww];
-                }
-            } else {
-                v[0] = m;
-#pragma unroll
-                for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) v[1] += sm[(ww * 16 + i) * LS + HD + 1] * f[ww];   // the running sum l
-            }
-            const unsigned long long lo = (unsigned long long)__builtin_bit_cast(unsigned, v[0]) | ((unsigned long long)__builtin_bit_cast(unsigned, v[1]) << 32);
-            const unsigned long long hi = (unsigned long long)__builtin_bit_cast(unsigned, v[2]) | ((unsigned long long)__builtin_bit_cast(unsigned, v[3]) << 32);
-            unsigned long long* dstp = (unsigned long long*)(rowp + d);
-            if (fused) {                                             // sc1: write-through
-                __hip_atomic_store(dstp, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (q < HD / 4) __hip_atomic_store(dstp + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                dstp[0] = lo;
-                if (q < HD / 4) dstp[1] = hi;
-            }
-        }
+        lsk_attn_merge_wide<HD, 8, FUSED>(sm, p.part, n_rows, M, inv_m, head0, p.max_pages, page_l, tid);
     }
     if (!fused) { LSK_TRACE_FLUSH(p, col * p.n_pages + page_l); return; }
     LSK_TRACE_POINT(4);                                           // partial stores issued
@@ -347,53 +421,10 @@ __device__ __forceinline__ void lsk_attn_body(const AttnHot& hp, const AttnSplit
             const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
             *(unsigned*)(p.out + (size_t)r * p.ldo + head * HD + d) = packed;
         }
+    } else if (n_rows * (HD / 4) <= LSK_ATTN_THREADS) {
+        lsk_attn_combine_wide<HD, 4>(p.part, p.out, p.ldo, n_rows, M, inv_m, head0, p.max_pages, base_pos, tid);
     } else {
-        for (int e = tid; e < n_rows * (HD / 4); e += LSK_ATTN_THREADS) {
-            const int i = e / (HD / 4);
-            const int d = (e - i * (HD / 4)) * 4;
-            const int ih = (i * inv_m) >> 8;
-            const int r = i - ih * M;
-            const int head = head0 + ih;
-            const float* base = p.part + ((size_t)head * p.max_pages) * LSK_ROWS * PSTRIDE;
-            const int n_pages = (base_pos + r) / LSK_ATTN_PAGE + 1;
-            float m = LSK_ATTN_NEG, l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int p0 = 0; p0 < n_pages; p0 += 8) {
-                float mo[8], lo[8], x0[8], x1[8], x2[8], x3[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int pg = min(p0 + k, n_pages - 1);
-                    const float* src = base + ((size_t)pg * LSK_ROWS + r) * PSTRIDE;
-                    // (max, sum) and the features are 8-byte aligned pairs (row stride (HD + 2) * 4 B, d even)
-                    const unsigned long long ml = __hip_atomic_load((const unsigned long long*)(src + HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long xa = __hip_atomic_load((const unsigned long long*)(src + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long xb = __hip_atomic_load((const unsigned long long*)(src + d + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    mo[k] = __builtin_bit_cast(float, (unsigned)ml);
-                    lo[k] = __builtin_bit_cast(float, (unsigned)(ml >> 32));
-                    x0[k] = __builtin_bit_cast(float, (unsigned)xa);
-                    x1[k] = __builtin_bit_cast(float, (unsigned)(xa >> 32));
-                    x2[k] = __builtin_bit_cast(float, (unsigned)xb);
-                    x3[k] = __builtin_bit_cast(float, (unsigned)(xb >> 32));
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (p0 + k < n_pages) {
-                        const float mn = fmaxf(m, mo[k]);
-                        const float fa = __builtin_amdgcn_exp2f(m - mn);
-                        const float fb = __builtin_amdgcn_exp2f(mo[k] - mn);
-                        l = l * fa + lo[k] * fb;
-                        a0 = a0 * fa + x0[k] * fb;
-                        a1 = a1 * fa + x1[k] * fb;
-                        a2 = a2 * fa + x2[k] * fb;
-                        a3 = a3 * fa + x3[k] * fb;
-                        m = mn;
-                    }
-                }
-            }
-            const elem_t o0 = f2e(a0 / l), o1 = f2e(a1 / l), o2 = f2e(a2 / l), o3 = f2e(a3 / l);
-            const unsigned long long packed = (unsigned long long)__builtin_bit_cast(unsigned short, o0) | ((unsigned long long)__builtin_bit_cast(unsigned short, o1) << 16) |
-                                              ((unsigned long long)__builtin_bit_cast(unsigned short, o2) << 32) | ((unsigned long long)__builtin_bit_cast(unsigned short, o3) << 48);
-            *(unsigned long long*)(p.out + (size_t)r * p.ldo + head * HD + d) = packed;
-        }
+        lsk_attn_combine_wide<HD, 8>(p.part, p.out, p.ldo, n_rows, M, inv_m, head0, p.max_pages, base_pos, tid);
     }
     if (tid == 0) __hip_atomic_store(p.counters + col, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef LSK_TRACE

@@ -7,13 +7,21 @@
 #include "lsk_gemm.h"
 
 static const size_t kMaxGemmLds = 160 * 1024;
-#define LSK_MB_MID 8              // rows of the middle template of the skinny projection kernel (1 | 8 | 16); a 7-row middle
+#define LSK_MB_MID 8              // rows of the middle template of the skinny projection kernel (1 | 8 | 10 | 13 | 16); a 7-row middle
                                   // template for 6 speculations measured no faster (profiles/r03_kernel_experiments.md)
+// 9 .. 13 rows (llama2-13B's 9-row and llama2-70B's 13-row verify passes, BASELINE configs #4 / #5) ran the 16-row template: every
+// thread requested 16 row slices per K-chunk -- 7 / 3 of them clamped duplicates -- IN FRONT of the weight ring at the top of the launch
+// and between its refills at every chunk boundary (K = 5120 .. 28672 is 2 .. 7 chunks): first weight 2 us later, body 2 us longer
+// (profiles/r04_timeline_13B.json).  The prologue is the only thing the template width changes (the MFMA tile is 16 rows either way).
+#define LSK_MB_9 10
+#define LSK_MB_11 13
 
 template <int PRO, int EPI>
 static int set_gemm_attr() {
     HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
     HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
     HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
     return 0;
 }
@@ -90,6 +98,8 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
     // profiling (ev_start != nullptr): the events are bound to THIS dispatch's own begin / end timestamps (what rocprofv3 reports)
     if (p.M == 1) launch_gemm_mb<PRO, EPI, 1>(p, grid, lds, st, ev_start, ev_stop);
     else if (p.M <= LSK_MB_MID) launch_gemm_mb<PRO, EPI, LSK_MB_MID>(p, grid, lds, st, ev_start, ev_stop);
+    else if (p.M <= LSK_MB_9) launch_gemm_mb<PRO, EPI, LSK_MB_9>(p, grid, lds, st, ev_start, ev_stop);
+    else if (p.M <= LSK_MB_11) launch_gemm_mb<PRO, EPI, LSK_MB_11>(p, grid, lds, st, ev_start, ev_stop);
     else launch_gemm_mb<PRO, EPI, 16>(p, grid, lds, st, ev_start, ev_stop);
     HIP_OK(hipGetLastError());
     if (grid_out) *grid_out = grid;

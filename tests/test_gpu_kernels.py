@@ -43,7 +43,7 @@ def _gemm(x, wp, n, norm_w=None, eps=1e-5, target_wgs=0):
 
 
 @pytest.mark.parametrize("m,k,n", [(1, 256, 64), (7, 4096, 512), (16, 4096, 1040), (3, 704, 256), (13, 11008, 320),
-                                   (5, 8192, 48), (16, 1408, 1000)])
+                                   (5, 8192, 48), (16, 1408, 1000), (9, 5120, 272), (10, 13824, 64), (11, 4096, 128)])
 def test_skinny_gemm_matches_fp32(gpu_device, m, k, n):
     """A = asymmetric random (transpose / row-swap detecting); fp32 accumulate => tight tolerance."""
     g = torch.Generator().manual_seed(m * 1000 + k + n)
@@ -97,6 +97,12 @@ def test_skinny_gemm_row_invariance(gpu_device):
         assert torch.equal(y1[0], y9[r])
     y9b = _gemm(x, wp, n, target_wgs=7)
     assert torch.equal(y9, y9b)
+    # every row template (1 | 8 | 10 | 13 | 16 rows, csrc/lsk_launch.h) gives the same bits for the same row
+    x16 = torch.randn(16, k, generator=g).to(torch.bfloat16).to(gpu_device)
+    y16 = _gemm(x16, wp, n)
+    for m in (2, 8, 9, 10, 11, 13, 14):
+        ym = _gemm(x16[:m].contiguous(), wp, n)
+        assert torch.equal(ym, y16[:m]), m
 
 
 @pytest.mark.parametrize("drafts,verified,eos,expect", [

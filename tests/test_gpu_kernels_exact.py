@@ -100,6 +100,8 @@ def _rope_table(shape_name, length, dev):
     ("tiny-mha", 2, 2, 128, 7, 0),         # first positions (cos = 1, sin = 0 at position 0)
     ("tiny-d64", 8, 2, 64, 5, 253),        # head_dim 64, llama3 frequency scaling, second page boundary
     ("tiny-gqa", 4, 2, 128, 1, 1151),      # one row on the LAST slot of page 8
+    ("tiny-gqa", 4, 2, 128, 9, 124),       # the 10-row template (llama2-13B's verify pass), across a page boundary
+    ("tiny-mha", 2, 2, 128, 13, 500),      # the 13-row template (llama2-70B's verify pass)
 ])
 def test_qkv_rope_kv_append_bit_exact(gpu_device, shape_name, n_heads, n_kv, hd, m, kv_len):
     from transformers.models.llama.modeling_llama import apply_rotary_pos_emb
@@ -157,7 +159,7 @@ def test_qkv_rope_kv_append_bit_exact(gpu_device, shape_name, n_heads, n_kv, hd,
     assert bool((kp.permute(0, 2, 1, 3)[~touched] == 7.0).all()) and bool((vp.permute(0, 3, 1, 2)[~touched] == 7.0).all())
 
 
-@pytest.mark.parametrize("m,H,I", [(1, 512, 1408), (7, 4096, 1024), (16, 5120, 256)])
+@pytest.mark.parametrize("m,H,I", [(1, 512, 1408), (7, 4096, 1024), (16, 5120, 256), (9, 5120, 512), (13, 8192, 256)])
 def test_swiglu_epilogue_bit_exact(gpu_device, m, H, I):
     lib, L = _lib()
     dev = gpu_device
@@ -182,7 +184,7 @@ def test_swiglu_epilogue_bit_exact(gpu_device, m, H, I):
     assert gate.unique().numel() > 10                                # the check is not vacuous
 
 
-@pytest.mark.parametrize("m,K,N", [(1, 4096, 4096), (7, 11008, 512), (16, 1408, 256)])
+@pytest.mark.parametrize("m,K,N", [(1, 4096, 4096), (7, 11008, 512), (16, 1408, 256), (9, 13824, 256), (13, 5120, 512)])
 def test_residual_epilogue_bit_exact(gpu_device, m, K, N):
     lib, L = _lib()
     dev = gpu_device
@@ -282,7 +284,7 @@ def _fill_pools(k, v, table, n_pages, n_kv, hd, dev, poison):
     return kpool.to(dev), vpool.to(dev)
 
 
-_GEOMS = [(1, 0), (1, 127), (7, 125), (16, 120), (16, 250), (7, 1140), (1, 1151), (16, 1136)]
+_GEOMS = [(1, 0), (1, 127), (7, 125), (16, 120), (16, 250), (7, 1140), (1, 1151), (16, 1136), (9, 700), (13, 1000)]   # 9 / 13 rows: the 8-wide merges
 _ATTN_CASES = [(mode, nh, nkv, hd, m, kv) for mode in (0, 1, 2) for (nh, nkv, hd) in [(4, 4, 128), (8, 2, 128), (8, 2, 64)]
                for (m, kv) in _GEOMS]
 _ATTN_CASES += [(mode, 32, 8, 128, m, kv) for mode in (0, 1, 2) for (m, kv) in [(7, 1140), (16, 120), (1, 127)]]   # llama3-8B heads
