@@ -36,7 +36,9 @@ extern "C" {
 #define LSK_ABI_VERSION 3   /* 2: options 4 / 6 removed, draft-block / sampled / profile-table entry points added, lsk_test_* moved to
                              liblayerskip_hip_test.so (include/layerskip_hip_test.h), lsk_engine_weights_checksum added
                              3: sample=True on the layer pipeline (lsk_draft_block_sampled, lsk_pipeline_pack_sampled,
-                             lsk_pipeline_tail_sampled, lsk_pipeline_residual, lsk_pipeline_result_words); message header 24 -> 40 words */
+                             lsk_pipeline_tail_sampled, lsk_pipeline_residual, lsk_pipeline_result_words); message header 24 -> 40 words;
+                             option 8 (the resident one-row grid) and lsk_engine_device_errors retired (profiles/r05_chain_resident_grid_retired.patch);
+                             lsk_engine_set_globals accepts NULL embed / final_norm / lm_head (middle pipeline ranks) */
 #define LSK_MAX_ROWS 16
 #define LSK_MAX_SPEC 15   /* num_speculations handled by one fused step (rows = spec + 1) */
 #define LSK_MAX_EOS 8
@@ -111,7 +113,8 @@ int lsk_engine_destroy(lsk_engine* e);
  * norm1 / norm2 are the plain bf16 RMSNorm gains (input_layernorm / post_attention_layernorm). */
 int lsk_engine_set_layer(lsk_engine* e, int32_t layer, const void* wqkv, const void* wo,
                          const void* wgu, const void* wdown, const void* norm1, const void* norm2);
-/* embed: plain bf16 [V][H]; final_norm: bf16 [H]; lm_head: PACKED [V][H];
+/* embed: plain bf16 [V][H]; final_norm: bf16 [H]; lm_head: PACKED [V][H] -- each may be NULL on a pipeline rank that never embeds a
+ * token / runs a head (a middle rank: checkpoint.load_layer_range(embed=False, head=False)); the entry points that need them say so;
  * rope_cos / rope_sin: bf16 [rope_len][head_dim/2] (host-precomputed exactly as
  * LlamaRotaryEmbedding.forward does, modeling_llama.py:113-127). */
 int lsk_engine_set_globals(lsk_engine* e, const void* embed, const void* final_norm,
@@ -250,16 +253,7 @@ int lsk_run_bulk(lsk_engine* e, int32_t n, int32_t layer_begin, int32_t layer_en
 #define LSK_OPT_GRAPH_STEPS 7     /* 1: lsk_spec_generate replays its steady-state steps from hipGraphs (cached per speculation count
                                      and KV page count) on a stream of the engine's own; identical tokens; default 0 -- the host is not
                                      the limiter */
-#define LSK_OPT_CHAIN 8           /* 1: one-row passes run o_proj -> gate/up -> down as ONE resident grid with a continuous weight stream
-                                   * (csrc/lsk_chain.h; bit-identical rows; needs the whole GPU: every workgroup resident at once).  Default 0:
-                                   * measured at parity with the three launches -- the two all-to-all edges cost what the boundaries cost
-                                   * (profiles/r04_chain_persistent_layer.md) */
 int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t value);
-/* Device-side error count since the last call (synchronises `stream`; clears): non-zero when a workgroup of the resident one-row
- * grid (LSK_OPT_CHAIN) gave up waiting for its peers -- the grid could not become co-resident (another process holds CUs of this
- * GPU) -- in which case the rows it produced are unusable: the host wrapper raises and tells the caller to set LSK_OPT_CHAIN 0.
- * (The reference has no such mode: torch launches never depend on co-residency.) */
-int lsk_engine_device_errors(lsk_engine* e, int32_t* count, void* stream);
 /* ---- sampling on the device (sample=True; GenerationConfig temperature / top_k / top_p, generator_base.py:35-44) ----
  * Both kernels are checked draw for draw against the oracle's model of them, and lsk_spec_step_sampled end to end against the
  * host-sampling path and the unmodified reference in distribution, on the GPU (tests/test_gpu_zz_sampling.py).  Parity with

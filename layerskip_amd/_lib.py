@@ -18,7 +18,6 @@ LSK_OPT_TARGET_WGS = 2
 LSK_OPT_FUSED_ATTN = 3
 LSK_OPT_FLASH_PREFILL = 5
 LSK_OPT_GRAPH_STEPS = 7       # steady-state greedy steps replayed from hipGraphs (default off)
-LSK_OPT_CHAIN = 8             # one-row passes: o_proj -> gate/up -> down as one resident grid (default off: parity with the launches, profiles/r04_chain_persistent_layer.md)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "liblayerskip_hip.so")            # bf16 build (BASELINE configs)
@@ -62,7 +61,6 @@ PROTOTYPES = {
     "lsk_engine_reset": (c_int32, [c_void_p, c_void_p]),
     "lsk_engine_set_kv_len": (c_int32, [c_void_p, c_int32, c_void_p]),
     "lsk_engine_get_kv_len": (c_int32, [c_void_p, POINTER(c_int32)]),
-    "lsk_engine_device_errors": (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
     "lsk_spec_step": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, POINTER(c_int32), c_int32,
                                 POINTER(LskStepResult), c_void_p]),
     "lsk_spec_generate": (c_int32, [c_void_p, POINTER(c_int32), c_int32, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32,

@@ -6,6 +6,10 @@ is one process per GPU with point-to-point hand-offs (layerskip_amd/pipeline.py)
 `[a, b)` plus the small shared tensors (embedding, final norm, lm_head: rank 0 drafts with its own head copy, the last rank runs
 the verify head) -- and must never pull the other 7/8 of a 140 GB checkpoint through its HBM.
 
+`--model` may be a directory or a hub id (`facebook/layerskip-llama2-7B`, the reference's usage, generate.py:59-64): a name that is
+not a directory is resolved to its snapshot directory through `huggingface_hub.snapshot_download` (config, tokenizer and safetensors
+files only; with HF_HUB_OFFLINE=1 that is a pure cache lookup).
+
 `load_layer_range` reads a `save_pretrained` / hub-layout directory (`config.json` + `model.safetensors` or the sharded
 `model-0000x-of-0000y.safetensors` with `model.safetensors.index.json`), opens only the shard files that hold tensors this rank
 owns and copies those tensors straight to the rank's device.  Decoder layers outside the range stay on the meta device (no
@@ -24,6 +28,21 @@ INDEX_NAME = "model.safetensors.index.json"
 SINGLE_NAME = "model.safetensors"
 
 
+def resolve_checkpoint_dir(path: str) -> str:
+    """A checkpoint DIRECTORY for what the reference hands to `from_pretrained` (generate.py:59-64): a local directory as it is, a hub id
+    (or anything else `from_pretrained` would accept by name) as its snapshot directory in the hub cache -- downloaded if the
+    environment allows it, looked up in the cache otherwise."""
+    if os.path.isdir(path):
+        return path
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(path, allow_patterns=["*.json", "*.safetensors", "tokenizer*", "*.model"])
+    except Exception as exc:       # noqa: BLE001 -- offline without a cached snapshot, a typo, a private repository ...
+        raise FileNotFoundError(f"{path!r} is neither a checkpoint directory nor a hub id that could be resolved to a snapshot directory "
+                                f"({type(exc).__name__}: {exc}).  Pass a `save_pretrained` directory, or populate the hub cache "
+                                f"(`huggingface-cli download {path}`); only safetensors checkpoints are read") from exc
+
+
 def _weight_map(path: str) -> Dict[str, str]:
     """tensor name -> file name (relative to `path`)."""
     index = os.path.join(path, INDEX_NAME)
@@ -39,13 +58,19 @@ def _weight_map(path: str) -> Dict[str, str]:
                             f"passes use_safetensors=True as well, generate.py:61)")
 
 
-def owned_parameter_names(names: Iterable[str], layer_range: Optional[Sequence[int]]) -> list:
-    """The parameters a rank materialises: its decoder layers and everything that is not a decoder layer."""
+def owned_parameter_names(names: Iterable[str], layer_range: Optional[Sequence[int]], embed: bool = True, head: bool = True) -> list:
+    """The parameters a rank materialises: its decoder layers, the (tiny) final norm, and -- where the rank uses them -- the embedding
+    (rank 0: the input rows and the drafted tokens) and the lm_head (rank 0: the draft head; the last rank: the verify head).  A middle
+    rank of a pipeline needs neither: 2 x 2.1 GB at llama3-70B that never have to cross its HBM."""
     out = []
     for name in names:
         if layer_range is not None and name.startswith("model.layers."):
             if not (layer_range[0] <= int(name.split(".")[2]) < layer_range[1]):
                 continue
+        if name == "model.embed_tokens.weight" and not embed:
+            continue
+        if name == "lm_head.weight" and not head:
+            continue
         out.append(name)
     return out
 
@@ -60,10 +85,12 @@ def _assign(model: torch.nn.Module, dotted: str, value: torch.Tensor) -> None:
 
 @torch.no_grad()
 def load_layer_range(path: str, layer_range: Optional[Sequence[int]] = None, device: str | torch.device = "cuda:0",
-                     dtype: torch.dtype = torch.bfloat16) -> transformers.LlamaForCausalLM:
-    """`LlamaForCausalLM` with decoder layers `[a, b)` (all of them for `layer_range=None`), the embedding, the final norm and
-    the lm_head on `device` in `dtype`; the other decoder layers on the meta device.  `model.loaded_layer_range` = (a, b)."""
+                     dtype: torch.dtype = torch.bfloat16, embed: bool = True, head: bool = True) -> transformers.LlamaForCausalLM:
+    """`LlamaForCausalLM` with decoder layers `[a, b)` (all of them for `layer_range=None`), the final norm and -- unless the caller
+    says this rank uses neither (`embed=False` / `head=False`: a middle rank of a pipeline) -- the embedding and the lm_head on `device`
+    in `dtype`; everything else on the meta device.  `path`: a directory or a hub id.  `model.loaded_layer_range` = (a, b)."""
     device = torch.device(device)
+    path = resolve_checkpoint_dir(path)
     config = transformers.AutoConfig.from_pretrained(path)
     if getattr(config, "model_type", "llama") != "llama":
         raise ValueError(f"{path}: model_type {config.model_type!r}; the engine implements the Llama decoder (SURVEY.md 8a)")
@@ -76,7 +103,8 @@ def load_layer_range(path: str, layer_range: Optional[Sequence[int]] = None, dev
     model.eval()
     wmap = _weight_map(path)
     tied = bool(getattr(config, "tie_word_embeddings", False))
-    wanted = owned_parameter_names([n for n, _ in model.named_parameters()], rng)
+    # a tied checkpoint's head IS its embedding: a rank that runs a head needs that tensor
+    wanted = owned_parameter_names([n for n, _ in model.named_parameters()], rng, embed=embed or (head and tied), head=head)
     by_file: Dict[str, list] = {}
     for name in wanted:
         if name == "lm_head.weight" and name not in wmap:
@@ -92,7 +120,7 @@ def load_layer_range(path: str, layer_range: Optional[Sequence[int]] = None, dev
         with safe_open(os.path.join(path, fname), framework="pt", device=str(device)) as f:
             for name in names:
                 _assign(model, name, f.get_tensor(name).to(dtype).contiguous())
-    if tied or model.lm_head.weight.device.type == "meta":
+    if head and (tied or model.lm_head.weight.device.type == "meta"):
         model.lm_head.weight = model.model.embed_tokens.weight
     # non-persistent buffers (rotary inv_freq) were created on the meta device: rebuild them
     model.model.rotary_emb = type(model.model.rotary_emb)(config).to(device)

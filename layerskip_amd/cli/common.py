@@ -59,7 +59,8 @@ def run_partition(args: Arguments, syn: SyntheticArguments, exit_layer: int, ctx
         e = exit_layer if exit_layer > 0 else -1
     else:
         import transformers
-        n_layers = transformers.AutoConfig.from_pretrained(args.model).num_hidden_layers
+        from ..checkpoint import resolve_checkpoint_dir
+        n_layers = transformers.AutoConfig.from_pretrained(resolve_checkpoint_dir(args.model)).num_hidden_layers
         e = exit_layer
     return partition_for(n_layers, e, ctx.world, syn.pp_balance)
 
@@ -85,9 +86,13 @@ def load_model_and_tokenizer(args: Arguments, syn: SyntheticArguments, exit_laye
         model = synthetic.build_model(cfg, seed=0, exit_layer=e, late_damping=syn.late_damping, dtype=torch.bfloat16,
                                       device=syn.device, gen_device=gen_device, layer_range=layer_range)
         return model, None
-    from ..checkpoint import load_layer_range
-    tokenizer = _load_tokenizer(args.model)
-    model = load_layer_range(args.model, layer_range, device=syn.device, dtype=torch.bfloat16)
+    from ..checkpoint import load_layer_range, resolve_checkpoint_dir
+    path = resolve_checkpoint_dir(args.model)          # a directory, or a hub id as the reference passes it (generate.py:59-64)
+    tokenizer = _load_tokenizer(path)
+    # rank 0 embeds and drafts with its own head copy, the last rank runs the verify head; a middle rank needs neither tensor
+    first = ctx is None or ctx.rank == 0
+    last = ctx is None or ctx.rank == ctx.world - 1
+    model = load_layer_range(path, layer_range, device=syn.device, dtype=torch.bfloat16, embed=first, head=first or last)
     return model, tokenizer
 
 

@@ -47,14 +47,6 @@ struct lsk_engine {
     float* samp_part_val = nullptr;
     int* samp_part_idx = nullptr;
     size_t samp_state_bytes = 0;                 // histograms + row states from samp_hist on: what must be zero between draws
-    // one-row passes: o_proj -> gate/up -> down as ONE resident grid (lsk_chain.h): granule rows of its two edges, the launch counter
-    // their tags come from, the option, the device error word (spin limit hit: the grid could not become co-resident)
-    unsigned long long* chain_g1 = nullptr;   // [hidden / 2]
-    unsigned long long* chain_g2 = nullptr;   // [intermediate / 2]
-    int* chain_err = nullptr;
-    unsigned chain_seq = 0;
-    bool chain = false;                       // LSK_OPT_CHAIN (default off: measured at parity with the three launches)
-    int chain_cus = 0;                        // CUs of the device (the grid must fit: one workgroup per CU)
     bool fused_attn = true;
     bool flash_prefill = true;    // prompt rows: one flash-shaped attention launch per layer instead of rows/16 decode launches
     elem_t *xn_bulk = nullptr, *q_bulk = nullptr, *attn_bulk = nullptr, *act_bulk = nullptr;   // prefill scratch [max_prompt+16][..]
@@ -91,8 +83,7 @@ struct lsk_engine {
 };
 
 // kernel classes of the decode path (lsk_engine_get_profile_table); each is split into 1-row and multi-row passes
-enum { LSK_PROF_QKV = 0, LSK_PROF_ATTN = 1, LSK_PROF_OPROJ = 2, LSK_PROF_GATEUP = 3, LSK_PROF_DOWN = 4, LSK_PROF_HEAD = 5, LSK_PROF_CHAIN = 6,
-       LSK_PROF_CLASSES = 7 };   // CHAIN: o_proj + gate/up + down of a one-row pass as one launch (lsk_chain.h)
+enum { LSK_PROF_QKV = 0, LSK_PROF_ATTN = 1, LSK_PROF_OPROJ = 2, LSK_PROF_GATEUP = 3, LSK_PROF_DOWN = 4, LSK_PROF_HEAD = 5, LSK_PROF_CLASSES = 6 };
 
 int lsk_check_cfg(const lsk_config* c);
 // rows of a hidden-state buffer (0 = step rows, 1 = bulk / prompt rows, 2 = pipeline message rows) and their capacity

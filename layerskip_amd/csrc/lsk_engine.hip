@@ -6,7 +6,6 @@
 
 #include "lsk_engine.h"
 #include "lsk_launch.h"
-#include "lsk_chain.h"
 #include "lsk_gemm_big.h"
 #include "lsk_small.h"
 
@@ -37,7 +36,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
     size_t state, zero, block_table, row_tokens, verified, eos, result, bulk_ids, part_val, part_idx, hrow, hmsg, hbulk, qbuf,
-        attn, act, attn_part, attn_cnt, chain_g1, chain_g2, chain_err, xn_bulk, q_bulk, attn_bulk, act_bulk, samp_hist, samp_cnt, samp_rows, samp_coarse, samp_part_val, samp_part_idx, total;
+        attn, act, attn_part, attn_cnt, xn_bulk, q_bulk, attn_bulk, act_bulk, samp_hist, samp_cnt, samp_rows, samp_coarse, samp_part_val, samp_part_idx, total;
     bool samp_big;
     int max_parts, n_pages;
 };
@@ -80,9 +79,6 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.act = take(2 * (size_t)LSK_MAX_ROWS * c->intermediate);
     L.attn_part = take(sizeof(float) * (size_t)c->n_heads * L.n_pages * LSK_MAX_ROWS * (c->head_dim + 2));
     L.attn_cnt = take(sizeof(int) * (size_t)(c->n_heads + 16));   // arrival tickets per head column
-    L.chain_g1 = take(sizeof(unsigned long long) * (size_t)(c->hidden / 2));
-    L.chain_g2 = take(sizeof(unsigned long long) * (size_t)(c->intermediate / 2));
-    L.chain_err = take(64);
     L.xn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->hidden);
     L.q_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
     L.attn_bulk = take(2 * (size_t)(c->max_prompt + 16) * c->n_heads * c->head_dim);
@@ -173,9 +169,6 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     e->act = (elem_t*)(e->ws + L.act);
     e->attn_part = (float*)(e->ws + L.attn_part);
     e->attn_cnt = (int*)(e->ws + L.attn_cnt);
-    e->chain_g1 = (unsigned long long*)(e->ws + L.chain_g1);
-    e->chain_g2 = (unsigned long long*)(e->ws + L.chain_g2);
-    e->chain_err = (int*)(e->ws + L.chain_err);
     e->xn_bulk = (elem_t*)(e->ws + L.xn_bulk);
     e->q_bulk = (elem_t*)(e->ws + L.q_bulk);
     e->attn_bulk = (elem_t*)(e->ws + L.attn_bulk);
@@ -202,14 +195,6 @@ extern "C" int lsk_engine_create(const lsk_config* cfg, void* workspace, size_t 
     if (err == hipSuccess) err = hipMemset(e->state, 0, sizeof(StepState));
     if (err == hipSuccess) err = hipMemset(e->zero, 0, 64);
     if (err == hipSuccess) err = hipMemset(e->attn_cnt, 0, sizeof(int) * (cfg->n_heads + 16));
-    // granule rows start with tag 0 (no launch ever carries it); the error word starts clear
-    if (err == hipSuccess) err = hipMemset(e->chain_g1, 0, L.xn_bulk - L.chain_g1);
-    if (err == hipSuccess) {
-        int dev = 0, cus = 0;
-        err = hipGetDevice(&dev);
-        if (err == hipSuccess) err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        e->chain_cus = cus;
-    }
     if (err == hipSuccess && L.samp_big) err = hipMemset(e->samp_hist, 0, e->samp_state_bytes);   // histograms + row states
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->host_result, sizeof(int) * 128, hipHostMallocDefault);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->step_done[0], hipEventDisableTiming);
@@ -244,7 +229,10 @@ extern "C" int lsk_engine_set_layer(lsk_engine* e, int32_t layer, const void* wq
 
 extern "C" int lsk_engine_set_globals(lsk_engine* e, const void* embed, const void* final_norm, const void* lm_head, const void* rope_cos,
                                       const void* rope_sin, int32_t rope_len) {
-    if (!e || !embed || !final_norm || !lm_head || !rope_cos || !rope_sin) return lsk_fail("lsk_engine_set_globals: null pointer");
+    // embed / final_norm / lm_head may be NULL on a pipeline rank that never embeds a token or runs a head (a middle rank): the entry points
+    // that need them say so (lsk_embed_rows_dev, lsk_run_head_dev)
+    if (!e || !rope_cos || !rope_sin) return lsk_fail("lsk_engine_set_globals: null pointer");
+    if ((lm_head != nullptr) != (final_norm != nullptr)) return lsk_fail("lsk_engine_set_globals: the lm_head and the final norm come together");
     if (rope_len < e->cfg.max_ctx) return lsk_fail("rope table (%d) shorter than max_ctx (%d)", rope_len, e->cfg.max_ctx);
     e->embed = (const elem_t*)embed; e->final_norm = (const elem_t*)final_norm; e->lm_head = (const elem_t*)lm_head;
     e->rope_cos = (const elem_t*)rope_cos; e->rope_sin = (const elem_t*)rope_sin; e->rope_len = rope_len;
@@ -347,7 +335,7 @@ extern "C" int lsk_engine_get_kv_len(lsk_engine* e, int32_t* kv_len) {
 // ------------------------------------------------------------------------------------------------
 int lsk_ready(lsk_engine* e) {
     if (!e) return lsk_fail("null engine");
-    if (!e->embed) return lsk_fail("engine globals not bound (lsk_engine_set_globals)");
+    if (!e->rope_cos) return lsk_fail("engine globals not bound (lsk_engine_set_globals)");
     return 0;
 }
 
@@ -442,55 +430,6 @@ static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     return 0;
 }
 
-// One-row passes: o_proj + residual -> RMSNorm + gate/up + SiLU*mul -> down_proj + residual as ONE resident grid (lsk_chain.h).
-// Returns 1 through *used when the shape fits the kernel and the option is on; otherwise the caller launches the three kernels.
-static int launch_chain(lsk_engine* e, const LayerWeights& lw, elem_t* x, hipStream_t st, bool* used) {
-    *used = false;
-    const lsk_config& c = e->cfg;
-    if (!e->chain) return 0;
-    const int qdim = c.n_heads * c.head_dim;
-    const int tiles_h = c.hidden / 16, pairs = c.intermediate / 16;
-    const int tpw_h = tiles_per_wg(tiles_h, e->target_wgs), tpw_gu = 2 * tiles_per_wg(pairs, e->target_wgs);
-    const int grid_h = (tiles_h + tpw_h - 1) / tpw_h, grid_gu = (2 * pairs + tpw_gu - 1) / tpw_gu;
-    const int grid = grid_h > grid_gu ? grid_h : grid_gu;
-    const size_t lds = lsk_chain_lds_bytes(qdim, c.hidden, c.intermediate);
-    // every workgroup must be resident at once (one 12-wave workgroup per CU); rows the service waves' 64-bit masks cover; the
-    // two-chunk prologue of the attention row; 32-bit buffer offsets (as launch_gemm)
-    if (grid > e->chain_cus || lds > kMaxGemmLds || qdim > 2 * LSK_KC_ELEMS || c.hidden > 32768 || c.intermediate > 32768) return 0;
-    if ((c.hidden & 15) || (c.intermediate & 15) || (size_t)2 * c.intermediate * c.hidden * 2 >= (size_t)LSK_OOB_OFFSET) return 0;
-    static std::mutex mu;
-    static unsigned long long attr_mask = 0;
-    {
-        int dev = 0;
-        HIP_OK(hipGetDevice(&dev));
-        std::lock_guard<std::mutex> lock(mu);
-        if (!(dev >= 0 && dev < 64 && (attr_mask >> dev) & 1ull)) {
-            HIP_OK(hipFuncSetAttribute((const void*)lsk_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-            if (dev >= 0 && dev < 64) attr_mask |= 1ull << dev;
-        }
-    }
-    ChainParams p{};
-    p.attn = e->attn; p.h = x; p.wo = lw.wo; p.wgu = lw.wgu; p.wdown = lw.wdown; p.norm_w = lw.norm2;
-    p.wo_bytes = (unsigned)((size_t)c.hidden * qdim * 2);
-    p.wgu_bytes = (unsigned)((size_t)2 * c.intermediate * c.hidden * 2);
-    p.wdown_bytes = (unsigned)((size_t)c.hidden * c.intermediate * 2);
-    p.qdim = qdim; p.hidden = c.hidden; p.inter = c.intermediate; p.tpw_h = tpw_h; p.tpw_gu = tpw_gu; p.eps = c.rms_eps;
-    p.g1 = e->chain_g1; p.g2 = e->chain_g2; p.err = e->chain_err;
-    e->chain_seq += 2;
-    if (e->chain_seq == 0) e->chain_seq = 2;                       // tag 0 = "never written"
-    p.tag = e->chain_seq;
-#ifdef LSK_TRACE
-    p.trace = lsk_trace_next(2, 0, 1, grid);
-#endif
-    hipEvent_t ea = nullptr, eb = nullptr;
-    LSK_TRY(profile_pair(e, LSK_PROF_CHAIN, 1, (double)p.wo_bytes + (double)p.wgu_bytes + (double)p.wdown_bytes, &ea, &eb));
-    if (ea != nullptr) hipExtLaunchKernelGGL(lsk_chain_kernel, dim3(grid), dim3(LSK_CHAIN_THREADS), lds, st, ea, eb, 0, p);
-    else hipLaunchKernelGGL(lsk_chain_kernel, dim3(grid), dim3(LSK_CHAIN_THREADS), lds, st, p);
-    HIP_OK(hipGetLastError());
-    *used = true;
-    return 0;
-}
-
 // decoder layers [lb, le) in place over rows of `x` (positions *base_ptr + pos_off + i)
 int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st) {
     const lsk_config& c = e->cfg;
@@ -514,11 +453,6 @@ int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int
             LSK_TRY((launch_gemm<PRO_RMS, EPI_QKV>(p, e->target_wgs, st, nullptr, ea, eb)));
         }
         LSK_TRY(launch_attn(e, e->qbuf, e->attn, kpool, vpool, m, pos_off, st));
-        if (m == 1) {
-            bool chained = false;
-            LSK_TRY(launch_chain(e, lw, x, st, &chained));
-            if (chained) continue;
-        }
         {   // o_proj + residual
             GemmParams p{};
             p.x = e->attn; p.ldx = qdim; p.M = m; p.K = qdim; p.N = c.hidden; p.n_tiles = p.N / 16;
@@ -554,6 +488,8 @@ int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int
 int lsk_run_head_dev(lsk_engine* e, const elem_t* x, int m, float* logits, int ld_logits, int* tokens_dev, hipStream_t st,
                      elem_t* embed_dst) {
     const lsk_config& c = e->cfg;
+    if (!e->lm_head || !e->final_norm) return lsk_fail("the final norm / lm_head are not bound on this engine (a middle pipeline rank runs no head)");
+    if (embed_dst != nullptr && !e->embed) return lsk_fail("the embedding is not bound on this engine");
     GemmParams p{};
     p.x = x; p.ldx = c.hidden; p.M = m; p.K = c.hidden; p.N = c.vocab; p.n_tiles = (c.vocab + 15) / 16;
     p.wp = e->lm_head; p.wp_bytes = (unsigned)((size_t)p.n_tiles * 16 * p.K * 2);
@@ -572,6 +508,7 @@ int lsk_run_head_dev(lsk_engine* e, const elem_t* x, int m, float* logits, int l
 }
 
 int lsk_embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, elem_t* dst, hipStream_t st) {
+    if (!e->embed) return lsk_fail("the embedding is not bound on this engine (only rank 0 of a pipeline embeds tokens)");
     hipLaunchKernelGGL(lsk_embed_kernel, dim3(n), dim3(256), 0, st, e->embed, tokens_dev, e->cfg.hidden, e->cfg.vocab, dst);
     HIP_OK(hipGetLastError());
     return 0;
@@ -737,20 +674,8 @@ extern "C" int lsk_engine_set_option(lsk_engine* e, int32_t option, int32_t valu
         case LSK_OPT_FUSED_ATTN: e->fused_attn = value != 0; return 0;
         case LSK_OPT_FLASH_PREFILL: e->flash_prefill = value != 0; return 0;
         case LSK_OPT_GRAPH_STEPS: e->graph_steps = value != 0; return 0;
-        case LSK_OPT_CHAIN: e->chain = value != 0; return 0;
         default: return lsk_fail("unknown option %d", option);
     }
-}
-
-extern "C" int lsk_engine_device_errors(lsk_engine* e, int32_t* count, void* stream) {
-    if (!e || !count) return lsk_fail("lsk_engine_device_errors: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    int v = 0;
-    HIP_OK(hipMemcpyAsync(&v, e->chain_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    if (v != 0) HIP_OK(hipMemsetAsync(e->chain_err, 0, sizeof(int), st));
-    *count = v;
-    return 0;
 }
 
 extern "C" int lsk_run_head(lsk_engine* e, int32_t buffer, int32_t row_base, int32_t m, void* logits_out, int32_t ld_logits,

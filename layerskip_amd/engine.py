@@ -65,7 +65,8 @@ class HipEngine:
     def __init__(self, model, max_ctx: int = 2048, max_prompt: int = 1024, page_size: int = 128,
                  target_wgs: int = 0, layer_range: Optional[Sequence[int]] = None, release_weights: bool = False):
         cfg = model.config
-        weight = model.model.embed_tokens.weight
+        # (the final norm is the one tensor every rank of a pipeline materialises: a middle rank holds neither the embedding nor the head)
+        weight = model.model.norm.weight if model.model.embed_tokens.weight.is_meta else model.model.embed_tokens.weight
         dmap = getattr(model, "hf_device_map", None)
         if dmap and len(set(dmap.values())) > 1:
             # the reference's multi-GPU form (generate.py:59-64): ONE process, layers spread by accelerate hooks
@@ -119,10 +120,6 @@ class HipEngine:
             self._pack_weights(model)
             self._allocate(max_ctx, max_prompt)
         self._fingerprint = self._weights_fingerprint(model)
-        if os.environ.get("LSK_CHAIN") == "1":
-            # the resident one-row grid (csrc/lsk_chain.h): opt-in -- it needs every CU of the GPU at once, and it measured at parity
-            # with the three launches it replaces (profiles/r04_chain_persistent_layer.md)
-            self.set_option(_lib.LSK_OPT_CHAIN, 1)
 
     @property
     def model(self):
@@ -139,7 +136,7 @@ class HipEngine:
             a, mlp = layer.self_attn, layer.mlp
             out += [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight,
                     mlp.down_proj.weight, layer.input_layernorm.weight, layer.post_attention_layernorm.weight]
-        out += [m.lm_head.weight, m.model.embed_tokens.weight, m.model.norm.weight]
+        out += [t for t in (m.lm_head.weight, m.model.embed_tokens.weight, m.model.norm.weight) if not t.is_meta]
         return out
 
     def _weights_fingerprint(self, m):
@@ -228,16 +225,20 @@ class HipEngine:
                 for lin in (a.q_proj, a.k_proj, a.v_proj, a.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
                     lin.weight = torch.nn.Parameter(torch.empty(0, dtype=self.dtype, device=self.device),
                                                     requires_grad=False)
-        head = self._packed_buffer(self.vocab, H)
-        self._pack_into(head, m.lm_head.weight, 0, 1, 0)
-        self._globals["lm_head"] = head
-        tied = m.lm_head.weight.data_ptr() == m.model.embed_tokens.weight.data_ptr()
-        if self.release_weights and not tied:
-            torch.cuda.synchronize(self.device)
-            m.lm_head.weight = torch.nn.Parameter(torch.empty(0, dtype=self.dtype, device=self.device),
-                                                  requires_grad=False)
-        self._globals["embed"] = m.model.embed_tokens.weight.detach().contiguous()
-        self._globals["final_norm"] = m.model.norm.weight.detach().contiguous()
+        # a pipeline rank that runs no head / embeds no token (checkpoint.load_layer_range(embed=False, head=False)) leaves them on meta
+        have_head, have_embed = not m.lm_head.weight.is_meta, not m.model.embed_tokens.weight.is_meta
+        self._globals["lm_head"] = None
+        if have_head:
+            head = self._packed_buffer(self.vocab, H)
+            self._pack_into(head, m.lm_head.weight, 0, 1, 0)
+            self._globals["lm_head"] = head
+            tied = have_embed and m.lm_head.weight.data_ptr() == m.model.embed_tokens.weight.data_ptr()
+            if self.release_weights and not tied:
+                torch.cuda.synchronize(self.device)
+                m.lm_head.weight = torch.nn.Parameter(torch.empty(0, dtype=self.dtype, device=self.device),
+                                                      requires_grad=False)
+        self._globals["embed"] = m.model.embed_tokens.weight.detach().contiguous() if have_embed else None
+        self._globals["final_norm"] = m.model.norm.weight.detach().contiguous() if have_head else None
         torch.cuda.synchronize(self.device)
 
     def _rope_tables(self, length: int):
@@ -293,9 +294,9 @@ class HipEngine:
             self._ck(self.lib.lsk_engine_set_layer(handle, i, wqkv.data_ptr(), wo.data_ptr(), wgu.data_ptr(),
                                                 wdown.data_ptr(), n1.data_ptr(), n2.data_ptr()))
         g = self._globals
-        self._ck(self.lib.lsk_engine_set_globals(handle, g["embed"].data_ptr(), g["final_norm"].data_ptr(),
-                                              g["lm_head"].data_ptr(), self._buffers["cos"].data_ptr(),
-                                              self._buffers["sin"].data_ptr(), self.max_ctx))
+        ptr = lambda t: t.data_ptr() if t is not None else None          # noqa: E731 -- NULL: not bound on this rank
+        self._ck(self.lib.lsk_engine_set_globals(handle, ptr(g["embed"]), ptr(g["final_norm"]), ptr(g["lm_head"]),
+                                              self._buffers["cos"].data_ptr(), self._buffers["sin"].data_ptr(), self.max_ctx))
 
     def ensure_capacity(self, total_tokens: int, prompt_len: int) -> None:
         """Grow the KV pool / prompt buffer if a request needs more (context is lost)."""
@@ -313,16 +314,6 @@ class HipEngine:
             self.close()
         except Exception:
             pass
-
-    def _check_device(self) -> None:
-        """Raise if a kernel reported a device-side failure since the last check (one 4-byte read; the callers have just
-        synchronised anyway).  Today: the resident one-row grid (LSK_OPT_CHAIN) could not become co-resident."""
-        n = ctypes.c_int32(0)
-        self._ck(self.lib.lsk_engine_device_errors(self._handle, ctypes.byref(n), self._stream))
-        if n.value:
-            raise _lib.LskError(f"{n.value} workgroups of the resident one-row grid gave up waiting for their peers: the GPU is shared "
-                                f"with another process (the grid needs every CU).  Decode with engine.set_option(LSK_OPT_CHAIN, 0) "
-                                f"(three launches per layer instead), or give the engine the GPU to itself; the tokens of this call are invalid")
 
     # ------------------------------------------------------------------ state
     def reset(self) -> None:
@@ -350,7 +341,6 @@ class HipEngine:
         res = LskStepResult()
         self._ck(self.lib.lsk_spec_step(self._handle, ids, len(input_ids), int(num_speculations), int(exit_layer),
                                      eos_arr, len(eos), ctypes.byref(res), self._stream))
-        self._check_device()
         n, s = res.num_matches, int(num_speculations)
         return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
                           list(res.draft_tokens[:s]), list(res.verified_tokens[: s + 1]))
@@ -367,7 +357,6 @@ class HipEngine:
         self._ck(self.lib.lsk_spec_generate(self._handle, ids, len(prompt_ids), int(num_speculations), int(exit_layer), eos_arr,
                                          len(eos), int(max_steps), out, ctypes.byref(n_out), ctypes.byref(tm), ctypes.byref(td),
                                          sd, sm, ctypes.byref(ns), self._stream))
-        self._check_device()
         steps = [(sd[i], sm[i]) for i in range(ns.value)]
         return list(out[: n_out.value]), tm.value, td.value, steps
 
@@ -407,7 +396,6 @@ class HipEngine:
                                              len(eos), float(temperature), int(top_k), float(top_p), int(seed) & (2 ** 64 - 1),
                                              int(offset) & (2 ** 64 - 1), scratch.data_ptr(), scratch.numel(), ctypes.byref(res),
                                              self._stream))
-        self._check_device()
         n, s = res.num_matches, int(num_speculations)
         return StepResult(n, res.num_drafts, res.next_token, res.kv_len, list(res.emitted[: n + 1]),
                           list(res.draft_tokens[:s]), list(res.verified_tokens[: s + 1]))
@@ -428,7 +416,6 @@ class HipEngine:
             float(temperature), int(top_k), float(top_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
             scratch.data_ptr(), scratch.numel(), out, ctypes.byref(n_out), ctypes.byref(tm), ctypes.byref(td), sd, sm,
             ctypes.byref(ns), self._stream))
-        self._check_device()
         steps = [(sd[i], sm[i]) for i in range(ns.value)]
         return list(out[: n_out.value]), tm.value, td.value, steps
 
@@ -441,7 +428,6 @@ class HipEngine:
         n_out = ctypes.c_int32(0)
         self._ck(self.lib.lsk_ar_generate(self._handle, ids, len(input_ids), int(layer_end or self.num_layers), eos_arr,
                                        len(eos), int(max_steps), out, ctypes.byref(n_out), self._stream))
-        self._check_device()
         return list(out[: n_out.value])
 
     def ar_step(self, input_ids: Sequence[int], layer_end: Optional[int] = None) -> int:
@@ -449,7 +435,6 @@ class HipEngine:
         tok = ctypes.c_int32(0)
         self._ck(self.lib.lsk_ar_step(self._handle, ids, len(input_ids), int(layer_end or self.num_layers),
                                    ctypes.byref(tok), self._stream))
-        self._check_device()
         return tok.value
 
     # ------------------------------------------------------------------ layer-range pipeline (rank-0 half of a step)
@@ -631,7 +616,7 @@ class HipEngine:
         self._ck(self.lib.lsk_engine_get_host_stats(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
         return {"enqueue_s": a.value, "wall_s": b.value, "steps": n.value}
 
-    PROFILE_CLASSES = ("qkv", "attention", "o_proj", "gate_up", "down", "lm_head", "chain")   # chain: o_proj + gate/up + down of a one-row pass, one launch
+    PROFILE_CLASSES = ("qkv", "attention", "o_proj", "gate_up", "down", "lm_head")
 
     def get_profile_table(self):
         """[{kernel, rows ("1" | ">1"), launches, ms, bytes}] for every decode-path kernel class since set_profile(True)."""

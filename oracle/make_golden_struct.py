@@ -5,7 +5,11 @@ argmax -- has a top-2 margin of at least MIN_MARGIN_ULP bf16 ulps in the referen
 
 Run in the build container only (needs /root/reference):
 
-    python oracle/make_golden_struct.py [--only NAME] [--check]
+    python oracle/make_golden_struct.py [--only NAME] [--check] [--dtype fp16]
+
+--dtype fp16: the same cases with the checkpoint converted to float16 -- the dtype the reference's CLI hard-codes
+(generate.py:59-64, `torch_dtype=torch.float16`) -- into tests/golden/struct_fp16/ (record key "fp16", next to the reference's
+fp32 run of the same weights as the common truth of the logits gate).
 
 Per case: build the deterministic checkpoint on the CPU; run the reference's SelfSpeculativeGenerationStrategy and
 AutoRegressiveGenerationStrategy (greedy, bf16; fp32 as well for the small shapes) through oracle/ref_shim.py; REQUIRE
@@ -35,6 +39,8 @@ from oracle import llama_oracle as lo  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 
 OUT_DIR = os.path.join(ROOT, "tests", "golden", "struct")
+OUT_DIR_FP16 = os.path.join(ROOT, "tests", "golden", "struct_fp16")
+LOW_DTYPE = ("bf16", torch.bfloat16)       # --dtype fp16 replaces it with ("fp16", torch.float16)
 MIN_MARGIN_ULP = 16.0      # required of EVERY decision of the reference's bf16 run (the judge asked for >= 8)
 
 
@@ -187,6 +193,8 @@ def one_dtype(ref, model_bf16, case, prompt, eos, dtype, inplace: bool, exact=No
 
 def build_case(ref, name, case, eos=None):
     case = resolved(case)
+    if LOW_DTYPE[0] == "fp16":
+        case.fp32 = True           # the fp16 logits gate is "as close to the fp32 truth as the reference's own fp16 run": always record it
     cfg = synthetic.make_config(case.shape)
     t0 = time.time()
     model = synthetic.build_structured_model(cfg, seed=case.seed, exit_layer=case.exit_layer, dtype=torch.bfloat16,
@@ -205,7 +213,7 @@ def build_case(ref, name, case, eos=None):
         "override_tokens": prog["override"],
     }
     big = sum(p.numel() for p in model.parameters()) > 2e9
-    dtypes = ([("fp32", torch.float32)] if case.fp32 else []) + [("bf16", torch.bfloat16)]
+    dtypes = ([("fp32", torch.float32)] if case.fp32 else []) + [LOW_DTYPE]
     exact = None
     for dname, dtype in dtypes:
         rec[dname], keep = one_dtype(ref, model, case, prompt, eos, dtype, inplace=big, exact=exact)
@@ -214,7 +222,7 @@ def build_case(ref, name, case, eos=None):
         print(f"  {name} {dname}: {len(r['spec_tokens'])} tokens, acceptance {r['acceptance_rate']:.3f}, spec==ar "
               f"{r['spec_equals_ar']}, min margin {r['min_margin_ulp']:.1f} ulp (draft {r['min_draft_margin_ulp']:.1f}), "
               f"reference spec {r['reference_spec_seconds']} s, build {build_s:.1f} s", flush=True)
-    b = rec["bf16"]
+    b = rec[LOW_DTYPE[0]]
     assert b["spec_equals_ar"], "the reference's own spec and AR outputs differ on a structured checkpoint"
     assert b["min_margin_ulp"] >= MIN_MARGIN_ULP and b["min_draft_margin_ulp"] >= MIN_MARGIN_ULP, \
         f"{name}: a decision of the reference run has a margin below {MIN_MARGIN_ULP} bf16 ulp -- pick another seed"
@@ -236,7 +244,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--only", default=None, help="comma-separated case names")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     args = ap.parse_args()
+    global LOW_DTYPE, OUT_DIR
+    if args.dtype == "fp16":
+        LOW_DTYPE, OUT_DIR = ("fp16", torch.float16), OUT_DIR_FP16
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
     ref = ref_shim.load_reference()
@@ -249,7 +261,7 @@ def main():
         eos = None
         if case.eos_from:
             with open(os.path.join(OUT_DIR, case.eos_from + ".json")) as f:
-                toks = json.load(f)["bf16"]["spec_tokens"]
+                toks = json.load(f)[LOW_DTYPE[0]]["spec_tokens"]
             k = next(i for i in range(case.eos_index, len(toks)) if toks[i] not in toks[:i])
             eos = [toks[k]]
         rec = build_case(ref, name, case, eos)
@@ -257,7 +269,7 @@ def main():
         if args.check:
             with open(path) as f:
                 old = json.load(f)
-            same = all(old[d][key] == rec[d][key] for d in ("bf16", "fp32") if d in old
+            same = all(old[d][key] == rec[d][key] for d in ("bf16", "fp16", "fp32") if d in old
                        for key in ("spec_tokens", "ar_tokens", "steps", "step_drafts", "logits", "early_logits"))
             print(("OK   " if same else "DIFF ") + name, flush=True)
             bad += 0 if same else 1

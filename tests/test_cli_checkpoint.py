@@ -332,3 +332,35 @@ def test_loader_error_paths_name_the_problem(tmp_path, ckpt):
     json.dump(cfg, open(other / "config.json", "w"))
     with pytest.raises((ValueError, KeyError)):
         load_layer_range(str(other), None, device="cpu")
+
+
+def test_a_hub_id_resolves_to_its_cached_snapshot_and_a_middle_rank_holds_neither_embedding_nor_head(ckpt, tmp_path, monkeypatch):
+    """`--model facebook/layerskip-llama2-7B` is how the reference is used (generate.py:59-64, README): a name that is not a directory is
+    resolved to the snapshot directory of the hub cache (offline: a cache lookup).  And a middle rank of a pipeline materialises its
+    layers and the final norm only: the embedding and the lm_head (2 x 2.1 GB at llama3-70B) stay on the meta device."""
+    import shutil
+    import huggingface_hub
+    from layerskip_amd.checkpoint import load_layer_range, resolve_checkpoint_dir
+    cache = tmp_path / "hub"
+    snap = cache / "models--acme--tiny-layerskip" / "snapshots" / "0123abcd"
+    snap.parent.mkdir(parents=True)
+    shutil.copytree(ckpt["path"], snap)
+    refs = cache / "models--acme--tiny-layerskip" / "refs"
+    refs.mkdir()
+    (refs / "main").write_text("0123abcd")
+    monkeypatch.setattr(huggingface_hub.constants, "HF_HUB_CACHE", str(cache))
+    monkeypatch.setattr(huggingface_hub.constants, "HF_HUB_OFFLINE", True)
+    assert os.path.samefile(resolve_checkpoint_dir("acme/tiny-layerskip"), snap)
+    assert resolve_checkpoint_dir(ckpt["path"]) == ckpt["path"]
+    part = load_layer_range("acme/tiny-layerskip", (2, 4), device="cpu", embed=False, head=False)        # a middle rank
+    assert part.model.embed_tokens.weight.is_meta and part.lm_head.weight.is_meta
+    assert not part.model.norm.weight.is_meta and not part.model.layers[2].mlp.up_proj.weight.is_meta
+    assert torch.equal(part.model.layers[3].self_attn.o_proj.weight, ckpt["model"].model.layers[3].self_attn.o_proj.weight)
+    last = load_layer_range("acme/tiny-layerskip", (4, 6), device="cpu", embed=False, head=True)          # the last rank: the verify head
+    assert last.model.embed_tokens.weight.is_meta and torch.equal(last.lm_head.weight, ckpt["model"].lm_head.weight)
+    with pytest.raises(FileNotFoundError, match="neither a checkpoint directory nor a hub id"):
+        resolve_checkpoint_dir("acme/not-in-the-cache")
+    # the CLI's loader takes the same name (tokenizer included)
+    from layerskip_amd.cli.common import Arguments, SyntheticArguments, load_model_and_tokenizer
+    model, tok = load_model_and_tokenizer(Arguments(model="acme/tiny-layerskip"), SyntheticArguments(device="cpu"), 3)
+    assert tok is not None and torch.equal(model.lm_head.weight, ckpt["model"].lm_head.weight)
