@@ -138,6 +138,87 @@ def test_sampled_pipeline_of_hip_engines_is_draw_for_draw_the_fused_engine(gpu_d
     assert any(n < td for td, n in want_steps) and any(n == td and td > 0 for td, n in want_steps)   # rejections AND full acceptances occurred
 
 
+def _fullsize_worker(rank, world, port, queue, model_name, prompt_len, max_steps, sampled):
+    """BASELINE config #4 at FULL size: every rank materialises only its layer range (device generator: the same bits in every
+    process), releases the unpacked originals as it packs them, and the ranks share device 0 over gloo on a 1-GPU box (one rank per
+    device over RCCL when the box has them: tools/pp_identity.py is the same run as a measurement tool)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    import datetime
+    one_per_gpu = torch.cuda.device_count() >= world
+    dev = torch.device("cuda", rank if one_per_gpu else 0)
+    torch.cuda.set_device(dev)
+    if one_per_gpu:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(minutes=10))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
+    try:
+        from layerskip_amd import synthetic
+        from layerskip_amd.engine import HipEngine
+        from layerskip_amd.pipeline import PipelineSpeculativeDecoder, Sampling, plan_partition
+        cfg = synthetic.make_config(model_name)
+        E, S = synthetic.default_exit_layer(model_name), synthetic.default_num_speculations(model_name)
+        part = plan_partition(cfg.num_hidden_layers, E, world, balance="memory")          # SURVEY 8e: [0, 20) + [20, 40)
+        model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=0.03, dtype=torch.bfloat16, device=dev, gen_device=dev,
+                                      layer_range=part[rank])
+        eng = HipEngine(model, max_ctx=prompt_len + max_steps + 2 * S + 32, max_prompt=prompt_len, layer_range=part[rank], release_weights=True)
+        dec = PipelineSpeculativeDecoder(eng, rank, world, part, E, comm_device=dev if one_per_gpu else torch.device("cpu"))
+        prompt = synthetic.make_prompt(cfg.vocab_size, prompt_len, 0) if rank == 0 else None
+        sm = Sampling(**SAMPLING) if (sampled and rank == 0) else None
+        res = dec.generate(prompt, [cfg.vocab_size], max_steps, S, sampling=sm)
+        if rank == 0:
+            queue.put((res.predicted_tokens, res.steps, [list(p) for p in part]))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sampled", [False, True])
+def test_llama2_13b_at_full_size_on_two_pipeline_ranks_equals_one_engine(gpu_device, sampled):
+    """BASELINE config #4 (llama2-13B, exit_layer 10, 8 speculations, 2 ranks: [0, 20) + [20, 40)) at FULL size, 128 new tokens of a
+    random-init checkpoint whose drafts ARE rejected (acceptance ~0.6): ids and the per-step (drafts, matches) trace identical to ONE
+    fused engine holding all 40 layers -- greedy, and under sample=True (the reference's default flags) draw for draw."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 64 * 2 ** 30:
+        pytest.skip("needs 64 GB of free HBM (2 x 13 GB of packed layer ranges, then 26 GB for the one-engine run)")
+    from layerskip_amd import synthetic
+    from layerskip_amd.engine import HipEngine
+    name, prompt_len, max_steps, world = "llama2-13B", 96, 128, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_fullsize_worker, args=(r, world, port, queue, name, prompt_len, max_steps, sampled)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tokens, steps, part = queue.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert part == [[0, 20], [20, 40]]
+    cfg = synthetic.make_config(name)
+    E, S = synthetic.default_exit_layer(name), synthetic.default_num_speculations(name)
+    model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=0.03, dtype=torch.bfloat16, device=gpu_device, gen_device=gpu_device)
+    eng = HipEngine(model, max_ctx=prompt_len + max_steps + 2 * S + 32, max_prompt=prompt_len, release_weights=True)
+    prompt = synthetic.make_prompt(cfg.vocab_size, prompt_len, 0)
+    if sampled:
+        sm = SAMPLING
+        want, _, _, want_steps = eng.spec_generate_sampled(prompt, S, E, [cfg.vocab_size], max_steps, sm["temperature"], sm["top_k"], sm["top_p"],
+                                                           sm["seed"], sm["offset"])
+    else:
+        want, _, _, want_steps = eng.spec_generate(prompt, S, E, [cfg.vocab_size], max_steps)
+    eng.close()
+    del eng, model
+    torch.cuda.empty_cache()
+    assert len(want) == max_steps and tokens == want
+    assert [tuple(t) for t in steps] == [tuple(t) for t in want_steps]
+    assert any(n < td for td, n in want_steps), "the run must contain rejected drafts"
+    assert all(td <= S for td, _ in want_steps) and max(td for td, _ in want_steps) == S        # 9-row verify blocks
+
+
 def _nccl_worker(rank, world, port, queue):
     """One rank per DEVICE, backend nccl (= RCCL): rows go straight from / into the engines' message buffers over xGMI."""
     import sys
