@@ -617,6 +617,15 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev, backend):
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
     dec = PipelineSpeculativeDecoder(engine, rank, world, part, E, comm_device=comm_dev)
     eos = [cfg.vocab_size]
+    # every point-to-point channel of the protocol is opened OUTSIDE the timed region, whatever --warmup says (RCCL creates a peer
+    # communicator at the first send / recv of a pair)
+    transport_warm_s = dec.warm_transport()
+    transport = {"backend": backend, "ranks": world, "devices_on_this_node": torch.cuda.device_count(), "warm_up_s": round(transport_warm_s, 3)}
+    if backend == "nccl":
+        try:
+            transport["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:       # noqa: BLE001
+            transport["rccl_version"] = None
 
     def one(i):
         prompt = synthetic.make_prompt(cfg.vocab_size, args.prompt_len, i) if rank == 0 else None
@@ -654,12 +663,18 @@ def pipeline_bench(args, cfg, E, S, rank, world, dev, backend):
             "acceptance_rate": round(sum(acc) / len(acc), 4) if acc else None,
             "config": {"workload": f"{args.model} shape, exit_layer={E}, num_speculations={S}, {args.prompt_len}-token prompt, "
                                    f"{args.max_steps} new tokens, batch 1, greedy, random-init weights (late damping {args.late_damping})",
-                       "strategy": "self_speculative", "parallelism": f"pp{world}: layer ranges {part}, " + ("RCCL point-to-point" if backend == "nccl" else
-                                                                                                f"{backend} point-to-point, ranks SHARING one GPU (plumbing run)")},
+                       "strategy": "self_speculative",
+                       "parallelism": f"pp{world}: layer ranges {part}, " + (f"RCCL {transport.get('rccl_version')} point-to-point, {world} ranks, one per GPU"
+                                                                             if backend == "nccl" else
+                                                                             f"{backend} point-to-point, {world} ranks SHARING one GPU (plumbing run)"),
+                       "transport": transport},
             "pipeline": {**hop_stats[0],
                          "hops": [{"rank": r, "layers": list(part[r]), "hop_enqueue_ms": st.get("hop_enqueue_ms"), "hop_wait_ms": st.get("hop_wait_ms"),
                                    "blocks": st.get("hops")} for r, st in enumerate(hop_stats) if r > 0],
                          "message_bytes_per_hop": (S + 2) * cfg.hidden_size * 2,
+                         "expected": "<= 1 x the one-GPU tokens/s: one sequence is a serial draft -> verify chain, every hop adds its latency "
+                                     "(read hop_wait_ms against tools/p2p_microbench.py); the pipeline buys CAPACITY, `replicas` is the throughput curve "
+                                     "(~N x) -- DESIGN.md section 6",
                          "note": "hop_enqueue_ms = host time from posting the receive to forwarding the block (its launches queue behind "
                                  "the receive); hop_wait_ms = time the host then waited for the header; the device applies the header's "
                                  "rollback itself (lsk_pipeline_apply), the last rank accepts on the device (lsk_pipeline_tail)"},

@@ -140,7 +140,7 @@ class PipelineSpeculativeDecoder:
         self.lb, self.le = self.partition[rank]
         self.E = exit_layer
         self.group = group
-        self.dev = comm_device if comm_device is not None else backend.device
+        self.dev = torch.device(comm_device if comm_device is not None else backend.device)
         self.direct = torch.device(self.dev).type == torch.device(backend.device).type      # send / recv straight on the engine's rows
         self.optimistic = optimistic and world > 1
         if self.partition[0][0] != 0 or self.partition[0][1] < exit_layer:
@@ -167,6 +167,27 @@ class PipelineSpeculativeDecoder:
         return s
 
     # ------------------------------------------------------------------ comm helpers
+    def warm_transport(self) -> float:
+        """Collective, once per process group: one dummy message over every edge the protocol uses -- rank r -> r + 1 down the chain and
+        last rank -> rank 0 for the result -- so that the transport's lazily created point-to-point channels (RCCL builds a communicator
+        per peer pair at its first send / recv: tens of milliseconds) exist BEFORE the first timed block moves.  Returns the seconds it
+        took on this rank."""
+        if self.world == 1:
+            return 0.0
+        t0 = time.perf_counter()
+        tok = torch.zeros(64, dtype=torch.int32, device=self.dev)
+        if self.rank > 0:
+            dist.recv(tok, src=self.rank - 1, group=self.group)
+        if self.rank < self.world - 1:
+            dist.send(tok, dst=self.rank + 1, group=self.group)
+        if self.rank == self.world - 1:
+            dist.send(tok, dst=0, group=self.group)
+        if self.rank == 0:
+            dist.recv(tok, src=self.world - 1, group=self.group)
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        return time.perf_counter() - t0
+
     def _rows_out(self, buffer: int, row_base: int, m: int, dst: int) -> None:
         view = self.be.rows_view(buffer, row_base, m)
         dist.send(view if self.direct else view.to(self.dev), dst=dst, group=self.group)

@@ -65,6 +65,7 @@ def _worker(rank, world, port, queue):
         model = synthetic.build_model(cfg, seed=1, exit_layer=E, late_damping=0.05, layer_range=part[rank])
         be = CpuStageBackend(model, layer_range=part[rank])
         dec = PipelineSpeculativeDecoder(be, rank, world, part, E)
+        assert dec.warm_transport() >= 0.0          # every point-to-point channel of the protocol opened before the first block moves
         prompt = synthetic.make_prompt(cfg.vocab_size, 21, 3)
         res = dec.generate(prompt if rank == 0 else None, [cfg.vocab_size], 18, S)
         # an EOS case: the 5th token of the free run becomes the eos id
