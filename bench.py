@@ -299,7 +299,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         avg_ms = ms / launches
         achieved = by / (ms * 1e-3) / 1e9
         traffic, source = None, None
-        for cand in ("r04_pmc_gateup.json", "r03_pmc_gateup.json", "r02_pmc_gateup.json", "r01_pmc_gateup.json"):
+        for cand in ("r05_pmc_gateup.json", "r04_pmc_gateup.json", "r03_pmc_gateup.json", "r02_pmc_gateup.json", "r01_pmc_gateup.json"):
             pmc = os.path.join(ROOT, "profiles", cand)
             if args.model == "llama2-7B" and os.path.exists(pmc):
                 # HBM bytes per launch need the PMC passes (rocprofv3 --pmc, separate runs): not collectable inside this run
@@ -309,8 +309,9 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         # rocprofv3's figure for the same kernel (launch-weighted AverageNs of the committed profile of this command): under the profiler
         # the kernel itself is ~2 % slower -- its preloaded kernel arguments are not delivered (profiles/r04_profile_summary.md)
         rocprof_ms, rocprof_src = None, None
-        stats_csv = os.path.join(ROOT, "profiles", "r04_kernel_stats_7B_spec.csv")
-        if args.model == "llama2-7B" and os.path.exists(stats_csv):
+        stats_csv = next((c for c in (os.path.join(ROOT, "profiles", n) for n in ("r05_kernel_stats_7B_spec.csv", "r04_kernel_stats_7B_spec.csv"))
+                          if os.path.exists(c)), "")
+        if args.model == "llama2-7B" and stats_csv:
             import csv
             tot = cnt = 0.0
             for r in csv.DictReader(open(stats_csv)):
@@ -318,7 +319,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
                     tot += float(r["Calls"]) * float(r["AverageNs"])
                     cnt += float(r["Calls"])
             if cnt:
-                rocprof_ms, rocprof_src = round(tot / cnt / 1e6, 5), "REPLAYED from profiles/r04_kernel_stats_7B_spec.csv (rocprofv3 --kernel-trace --stats of this command)"
+                rocprof_ms, rocprof_src = round(tot / cnt / 1e6, 5), f"REPLAYED from profiles/{os.path.basename(stats_csv)} (rocprofv3 --kernel-trace --stats of this command)"
         out["roofline"] = {
             "kernel": "lsk_gemm_kernel<PRO_RMS,EPI_SWIGLU> (post-attn RMSNorm + gate/up + SiLU*mul)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -391,9 +392,22 @@ def prefill_leg(args, cfg, engine):
     engine.reset()
     tflops = flops / best / 1e12
     fetch = None
-    pmc = os.path.join(ROOT, "profiles", "r05_prefill_fetch.json")
-    if args.model == "llama2-7B" and os.path.exists(pmc):
-        fetch = json.load(open(pmc))
+    for cand in ("r05_pmc_hbm_traffic.csv", "r04_pmc_hbm_traffic.csv"):
+        pmc = os.path.join(ROOT, "profiles", cand)
+        if args.model == "llama2-7B" and os.path.exists(pmc):
+            # HBM reads of the prefill projections over their packed weights (PMC FETCH_SIZE pass of a 512-token prompt, x2 gfx950
+            # correction): > 1 means weight panels re-fetched by several row blocks -- REPLAYED, the counters need their own rocprofv3 run
+            import csv
+            got = {}
+            for r in csv.DictReader(open(pmc)):
+                if "lsk_gemm_big_kernel<" in r["kernel"] and r["counter"] == "FETCH_SIZE" and r.get("hbm_read_bytes_x2"):
+                    epi = int(r["kernel"].split("lsk_gemm_big_kernel<")[1].split(",")[0])
+                    got[epi] = float(r["hbm_read_bytes_x2"])
+            weights = {1: (2 * H * nh * hd + 2 * H * I) / 2.0, 2: 2 * 2 * H * I, 3: 2 * H * (nh + 2 * nkv) * hd}     # EPI_RESID: o_proj / down average
+            if set(got) == {1, 2, 3}:
+                fetch = {"value": round((2 * got[1] + got[2] + got[3]) / (2 * weights[1] + weights[2] + weights[3]), 3),
+                         "source": f"REPLAYED from profiles/{cand} (rocprofv3 --pmc FETCH_SIZE, per launch, x2 gfx950 correction); not measured by this run"}
+            break
     return {"rows": rows, "ms": round(1e3 * best, 3), "tflops": round(tflops, 1), "peak_tflops": MFMA_PEAK_TFLOPS,
             "frac_of_mfma_peak": round(tflops / MFMA_PEAK_TFLOPS, 4), "flops": int(flops),
             "fetch_over_weights": fetch,
