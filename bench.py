@@ -145,7 +145,16 @@ def main():
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend=backend, timeout=limit)
+            # gloo announces its connections on the C++ stdout: keep rank 0's stdout to the ONE JSON line (the chatter goes to stderr)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend=backend, timeout=limit)
+                dist.barrier()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
 
     E = args.exit_layer or synthetic.default_exit_layer(args.model)
     S = args.num_speculations or synthetic.default_num_speculations(args.model)
