@@ -182,6 +182,10 @@ class HipPipelineSelfSpeculativeGenerationStrategy(GenerationStrategy):
             backend = self.backend_factory(model, self.partition[self.ctx.rank], **self.engine_kwargs)
             dec = PipelineSpeculativeDecoder(backend, self.ctx.rank, self.ctx.world, self.partition, self.partition[0][1],
                                              group=self.ctx.group, comm_device=self.ctx.comm_device, optimistic=self.optimistic)
+            # every rank builds its decoder exactly once per model (rank 0 at its first generation, the others in serve()): the one
+            # collective moment to open the protocol's peer channels, so that no generation -- and no timing of one -- pays for RCCL's
+            # lazy communicator set-up
+            dec.warm_transport()
             _DECODERS[model] = dec
         self._last = dec
         return dec
