@@ -539,8 +539,14 @@ static int launch_big(BigGemmParams& p, hipStream_t st) {
     return launch_big_pb<EPI, NTW, MT, 2, NW, PIN>(p, st);
 }
 
+#ifndef LSK_QKV_NTW
+#define LSK_QKV_NTW 2
+#endif
+#ifndef LSK_QKV_MT
+#define LSK_QKV_MT 4
+#endif
 static int launch_big_qkv(BigGemmParams& p, hipStream_t st) {
-    return p.M > 1024 ? launch_big<EPI_QKV, 2, 4, 2, 8, false>(p, st) : launch_big<EPI_QKV, 2, 4, 2, 4, false>(p, st);
+    return p.M > 1024 ? launch_big<EPI_QKV, 2, 4, 2, 8, false>(p, st) : launch_big<EPI_QKV, LSK_QKV_NTW, LSK_QKV_MT, 2, 4, false>(p, st);
 }
 
 static int launch_big_gateup(BigGemmParams& p, hipStream_t st) { return launch_big<EPI_SWIGLU, 2, 8, 2, 4, false>(p, st); }
