@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
             if (T >= p.n_tiles) continue;
             const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);
             const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
-            const int head = TT / tph;
+            const int head = TT >> lsk_tph_shift(hd);
             const int tt = TT - head * tph;
             const int j = tt * 8 + (c16 & 7);
 #pragma unroll
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
                         cs_raw[i] = p.rope_cos[(size_t)pos * (hd >> 1) + j];
                         sn_raw[i] = p.rope_sin[(size_t)pos * (hd >> 1) + j];
                     }
-                    if (kind != 0) pg[i] = p.block_table[pos / p.page_size];
+                    if (kind != 0) pg[i] = p.block_table[pos >> LSK_PAGE_SHIFT];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -263,10 +263,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
                         if (kind == 0) {
                             p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2e(v);
                         } else {
-                            const int slot = pos % p.page_size;
-                            const size_t hb = ((size_t)pg[i] * p.n_kv + head) * p.page_size * hd;
+                            const int slot = pos & (LSK_ATTN_PAGE - 1);
+                            const size_t hb = ((size_t)pg[i] * p.n_kv + head) * LSK_ATTN_PAGE * hd;
                             if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2e(v);        // K page  [slot][d]
-                            else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2e(v);         // V^T page [d][slot]
+                            else p.vpool[hb + (size_t)feat * LSK_ATTN_PAGE + slot] = f2e(v);       // V^T page [d][slot]
                         }
                     }
                 }
