@@ -208,7 +208,9 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         n_params = sum(p.numel() for p in transformers.LlamaForCausalLM(cfg).parameters())
     # the CPU generator gives the same bits on every box (= the checkpoint the reference fixture was recorded on); beyond 20 B
     # parameters (llama2-70B on one GPU) the device generator is used whatever --weights says (host memory, minutes)
-    cpu_weights = args.weights == "cpu" and n_params < 20e9
+    # (N > 1: N processes drawing 7 B parameters on the host cores at once would take minutes; the replicas use the device generator --
+    #  the CPU-drawn bits only matter to the N = 1 line's reference_parity leg)
+    cpu_weights = args.weights == "cpu" and n_params < 20e9 and world == 1
     if cpu_weights:
         torch.set_num_threads(min(32, os.cpu_count() or 1))
     model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=args.late_damping, dtype=torch.bfloat16,
