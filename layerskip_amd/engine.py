@@ -11,7 +11,6 @@ PyTorch is used for storage and stream handles only: every tensor here is a buff
 from __future__ import annotations
 
 import ctypes
-import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
