@@ -284,3 +284,55 @@ def test_pipeline_over_rccl_one_rank_per_gpu(world):
     assert tokens == want.predicted_tokens and rate == want.acceptance_rate
     assert [tuple(s) for s in steps] == [tuple(s) for s in strat.last_steps]
     assert all(st["hops"] == len(steps) + 1 for st in stats[1:])          # every late rank served every block and the stop message
+
+
+def test_sampled_pipeline_kernels_flag_a_protocol_out_of_step_and_check_their_buffers(gpu_device):
+    """One rank, the sampled pipeline's C-ABI calls by hand: (1) the last rank's acceptance kernel refuses a block whose header carries
+    another Philox offset than its own step counter says (result word 22; rank 0 raises on it -- a message out of step must not pass
+    as a draw); (2) with matching offsets the block is consistent and `lsk_pipeline_residual` leaves a block that is not pending
+    untouched; (3) a result buffer that is too small is an error, not an overrun."""
+    import ctypes
+    from layerskip_amd import _lib, synthetic
+    from layerskip_amd.engine import HipEngine
+    from layerskip_amd.pipeline import RES_ERROR, RES_PENDING
+    cfg = synthetic.make_config("tiny-gqa")
+    E, S = 3, 5
+    model = synthetic.build_model(cfg, seed=2, exit_layer=E, late_damping=0.2, dtype=torch.bfloat16, device=gpu_device, gen_device="cpu")
+    eng = HipEngine(model, max_ctx=512, max_prompt=64)
+    eng.set_eos([cfg.vocab_size - 1])
+    prompt = synthetic.make_prompt(cfg.vocab_size, 17, 1)
+    P = len(prompt)
+    T, K, TP, seed, off = 0.8, 0, 0.9, 99, 1234
+    for header_off, tail_off, want_error in ((off, off + 1, 1), (off, off, 0)):
+        eng.reset()
+        eng.draft_block_sampled(prompt, 0, S + 1, P - 1, E, False, T, K, TP, seed, header_off)
+        eng.run_bulk(P - 1, E, eng.num_layers)
+        eng.run_layers(0, 0, S + 1, P - 1, E, eng.num_layers)
+        eng.pipeline_pack_sampled(1, P, 0, S + 1, 0, header_off)
+        blk = eng.pipeline_tail_sampled(S + 1, T, K, TP, seed, tail_off).clone()
+        words = [int(v) for v in blk[:24].tolist()]
+        assert words[RES_ERROR] == want_error
+        if want_error:
+            continue
+        n, td = words[0], words[1]
+        assert 0 <= n <= td <= S and words[3] == P + n
+        drafts = eng.row_tokens(1, S)
+        assert words[4:4 + n] == drafts[:n]
+        assert words[RES_PENDING] == (1 if n < td else 0) and (words[2] == -1) == (n < td)
+        before = blk.clone()
+        eng.pipeline_residual(blk, 0, seed, tail_off)
+        after = [int(v) for v in blk[:24].tolist()]
+        if n < td:
+            assert after[RES_PENDING] == 0 and 0 <= after[2] < cfg.vocab_size and after[4 + n] == after[2]
+        else:
+            assert torch.equal(blk, before)                     # not pending: a no-op
+        q = blk[64:64 + cfg.vocab_size].view(torch.float32)
+        assert abs(float(q.sum()) - 1.0) < 1e-3 and float(q.min()) >= 0.0      # q_n is a probability row
+    small = torch.zeros(64, dtype=torch.int32, device=gpu_device)
+    scratch = eng._sampling_scratch()
+    rc = eng.lib.lsk_pipeline_tail_sampled(eng._handle, S + 1, ctypes.c_float(T), K, ctypes.c_float(TP), seed, off, scratch.data_ptr(), scratch.numel(),
+                                           small.data_ptr(), small.numel(), eng._stream)
+    assert rc != 0 and b"result block" in eng.lib.lsk_last_error()
+    with pytest.raises(_lib.LskError):
+        eng.pipeline_residual(torch.zeros(8, dtype=torch.int32, device=gpu_device), 0, seed, off)
+    eng.close()

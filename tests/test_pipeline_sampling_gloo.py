@@ -229,3 +229,22 @@ def test_pipeline_strategies_sampled_and_with_processors_equal_the_one_process_s
         assert got[name][0] == want.predicted_tokens, name
         assert got[name][1] == want.acceptance_rate, name
         assert len(want.predicted_tokens) == 16
+
+
+def test_a_block_whose_philox_offset_is_not_the_last_ranks_is_refused():
+    """The last rank counts steps on its own; a header that carries another Philox offset (a protocol out of step) sets the result
+    block's error word and rank 0 raises instead of emitting a token drawn from the wrong stream."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_stage_backend import CpuStageBackend
+    from layerskip_amd import synthetic
+    from layerskip_amd.pipeline import PipelineSpeculativeDecoder, Sampling
+    cfg, model = _model()
+    be = CpuStageBackend(model)
+    dec = PipelineSpeculativeDecoder(be, 0, 1, [(0, cfg.num_hidden_layers)], E)
+    inner = be.pipeline_tail_sampled
+    be.pipeline_tail_sampled = lambda m, t, k, p, seed, off: inner(m, t, k, p, seed, off + 7)
+    with pytest.raises(RuntimeError, match="out of step"):
+        dec.generate(synthetic.make_prompt(cfg.vocab_size, 9, 3), [cfg.vocab_size], 8, S, sampling=Sampling(**SAMPLING))
+    be.pipeline_tail_sampled = inner
+    ok = dec.generate(synthetic.make_prompt(cfg.vocab_size, 9, 3), [cfg.vocab_size], 8, S, sampling=Sampling(**SAMPLING))
+    assert len(ok.predicted_tokens) == 8                       # and the decoder is usable again afterwards
