@@ -335,6 +335,7 @@ class PipelineSpeculativeDecoder:
         self._rows_out(BUF_MSG, 0, self._S + 2, 1)
         self._inflight += 1                        # the last rank answers every message with one result block
         self._inflight_rows = (P - 1) + self._S + 1
+        self._shipped += 1
         return None
 
     def _answer(self) -> torch.Tensor:
@@ -369,7 +370,12 @@ class PipelineSpeculativeDecoder:
             self.be.pipeline_pack_sampled(0, 1, 0, 1, kv, self._sampling.offset)
         else:
             self.be.pipeline_pack(0, 1, 0, 1, kv)
-        self._inflight_rows = self._S + 1
+        # the late ranks expect the prompt rows in front of their FIRST message: a generation that ends before any block was shipped
+        # (an error on rank 0 ahead of its first step) sends them too -- whatever they hold -- so that nobody is left in a receive
+        p = self._P0 if self._shipped == 0 else 1
+        if p > 1:
+            self._rows_out(BUF_BULK, 0, p - 1, 1)
+        self._inflight_rows = (p - 1) + self._S + 1
         self._rows_out(BUF_MSG, 0, self._S + 2, 1)
         self._inflight += 1
         self._answer()                             # the late ranks answer every message; this one is discarded
@@ -417,6 +423,7 @@ class PipelineSpeculativeDecoder:
         self._inflight = 0
         self._inflight_rows = S + 1
         self._kv_host = 0
+        self._P0, self._shipped = P0, 0
         try:
             if driver is not None:
                 out = driver(self)

@@ -248,3 +248,51 @@ def test_a_block_whose_philox_offset_is_not_the_last_ranks_is_refused():
     be.pipeline_tail_sampled = inner
     ok = dec.generate(synthetic.make_prompt(cfg.vocab_size, 9, 3), [cfg.vocab_size], 8, S, sampling=Sampling(**SAMPLING))
     assert len(ok.predicted_tokens) == 8                       # and the decoder is usable again afterwards
+
+
+def _early_error_worker(rank, world, port, queue):
+    _setup(rank, world, port)
+    try:
+        from cpu_stage_backend import CpuStageBackend
+        from layerskip_amd import synthetic
+        from layerskip_amd.pipeline import PipelineSpeculativeDecoder, plan_partition
+        cfg = synthetic.make_config("tiny-mha")
+        part = plan_partition(cfg.num_hidden_layers, E, world)
+        _, model = _model(part[rank])
+        dec = PipelineSpeculativeDecoder(CpuStageBackend(model, layer_range=part[rank]), rank, world, part, E)
+        prompt = synthetic.make_prompt(cfg.vocab_size, 21, 3)
+
+        def boom(_dec):
+            raise ValueError("a logits processor failed before the first verify")
+
+        outcome = "no error"
+        try:
+            dec.generate(prompt if rank == 0 else None, [cfg.vocab_size], 12, S, driver=boom if rank == 0 else None)
+        except ValueError as exc:
+            outcome = str(exc)
+        # the pipeline is still in step: a normal generation follows on the same decoder
+        res = dec.generate(prompt if rank == 0 else None, [cfg.vocab_size], 12, S)
+        queue_item = (rank, outcome, res.predicted_tokens)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, queue_item)
+        if rank == 0:
+            queue.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_an_error_on_rank_0_before_its_first_block_leaves_nobody_in_a_receive(world):
+    """Rank 0 fails ahead of its first step (here: the slow path's driver raises): the stop message then carries the prompt rows the
+    late ranks expect in front of their first message, every rank returns, and the next generation on the same decoders is correct."""
+    got = _run(world, _early_error_worker, ())
+    by_rank = {r: (o, t) for r, o, t in got}
+    assert "logits processor failed" in by_rank[0][0]
+    assert all(by_rank[r][0] == "no error" for r in range(1, world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from layerskip_amd import synthetic
+    from oracle import llama_oracle as lo
+    cfg, model = _model()
+    with torch.inference_mode():
+        want = lo.self_speculative_generate(lo.OracleModel.from_hf(model.float()), synthetic.make_prompt(cfg.vocab_size, 21, 3), [cfg.vocab_size], 12, E, S)
+    assert by_rank[0][1] == want.predicted_tokens
