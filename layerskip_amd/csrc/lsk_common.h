@@ -29,8 +29,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LSK_ROWS 16
 #define LSK_ATTN_PAGE 128          // KV page size == keys per decode-attention workgroup
 #define LSK_PAGE_SHIFT 7           // log2(LSK_ATTN_PAGE): lsk_check_cfg refuses any other page size, so position -> (page, slot) is a shift and a mask in
-                                   // the kernels (a division by the runtime page_size field was a ~35-instruction VALU sequence per row and lane in
-                                   // the q/k/v epilogues: 32 of them per lane in the prefill kernel's, as many instructions as its whole K loop)
+                                   // the prefill kernel (a division by the runtime page_size field is a ~35-instruction VALU sequence per row and lane:
+                                   // 32 of them per lane in its q/k/v epilogue; the decode kernel's 8-row template has no register to spare for the change)
 static_assert((1 << LSK_PAGE_SHIFT) == LSK_ATTN_PAGE, "page shift");
 // 16-column tiles per head (head_dim 64 or 128 -> 4 or 8): tile index -> (head, tile in head) without a division
 __device__ __forceinline__ int lsk_tph_shift(int head_dim) { return head_dim == 128 ? 3 : 2; }

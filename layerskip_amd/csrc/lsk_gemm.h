@@ -348,21 +348,21 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
     if (nchunks > 1) lsk_load_chunk<PRO, MB>(hp, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);
     // (q/k/v: the block's fields the operand addresses need are read in ONE scalar clause -- hipcc issues it at the top of the kernel,
     // the pin only keeps it from sinking the reads to their uses, one dependent round trip each)
-    if (EPI == EPI_QKV) asm volatile("" : : "s"(kv_now), "s"(p.pos_off), "s"(p.rope_cos), "s"(p.rope_sin), "s"(p.block_table),
+    if (EPI == EPI_QKV) asm volatile("" : : "s"(kv_now), "s"(p.pos_off), "s"(p.rope_cos), "s"(p.rope_sin), "s"(p.block_table), "s"(p.page_size),
                                      "s"(p.n_heads), "s"(p.n_kv), "s"(p.head_dim));
     if (EPI == EPI_QKV) {
         base_pos = kv_now + p.pos_off;
         const int hd = p.head_dim;
         const int tph = hd >> 4;
         const int TT = tile0 + w;                               // cos / sin column: the same function of the tile index for q and k
-        const int tt = TT & (tph - 1);                          // tiles (whole heads of hd / 16 tiles each precede both ranges; tph is 4 or 8)
+        const int tt = TT - (TT / tph) * tph;                   // tiles (whole heads of hd / 16 tiles each precede both ranges)
         const int j = tt * 8 + (c16 & 7);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pos = base_pos + min(rg * 4 + i, M - 1);
             pre_a[i] = p.rope_cos[(size_t)pos * (hd >> 1) + j];
             pre_b[i] = p.rope_sin[(size_t)pos * (hd >> 1) + j];
-            pre_pg[i] = p.block_table[pos >> LSK_PAGE_SHIFT];
+            pre_pg[i] = p.block_table[pos / p.page_size];
         }
     }
 
@@ -469,7 +469,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
             const int nk_t = p.n_kv * tph;
             const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);
             const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
-            const int head = TT >> lsk_tph_shift(hd);
+            const int head = TT / tph;
             const int tt = TT - head * tph;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -494,10 +494,10 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
                         p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2e(v);
                     } else {
                         const int page = pre_pg[i];
-                        const int slot = pos & (LSK_ATTN_PAGE - 1);
-                        const size_t hb = ((size_t)page * p.n_kv + head) * LSK_ATTN_PAGE * hd;
+                        const int slot = pos % p.page_size;
+                        const size_t hb = ((size_t)page * p.n_kv + head) * p.page_size * hd;
                         if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2e(v);        // K page  [slot][d]
-                        else p.vpool[hb + (size_t)feat * LSK_ATTN_PAGE + slot] = f2e(v);       // V^T page [d][slot]
+                        else p.vpool[hb + (size_t)feat * p.page_size + slot] = f2e(v);         // V^T page [d][slot]
                     }
                 }
             }
