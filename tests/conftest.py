@@ -73,16 +73,29 @@ def load_struct(name):
         return json.load(f)
 
 
+_STRUCT_CPU_CACHE = {}      # llama2-7B's structured checkpoint is built on the host cores once per session (~40 s): the bf16 suite and the fp16 suite share it
+
+
 def build_struct_model(rec, device="cpu"):
     """The deterministic structured checkpoint of a record (CPU generator: the same bits on every box)."""
+    import copy
     import torch
     from layerskip_amd import synthetic
-    cfg = synthetic.make_config(rec["shape"])
-    model = synthetic.build_structured_model(cfg, seed=rec["seed"], exit_layer=rec["exit_layer"], dtype=torch.bfloat16,
-                                             device="cpu", **rec.get("knobs", {}))
+    key = (rec["shape"], rec["seed"], rec["exit_layer"], tuple(sorted(rec.get("knobs", {}).items())))
+    cached = _STRUCT_CPU_CACHE.get(key)
+    if cached is None:
+        cfg = synthetic.make_config(rec["shape"])
+        cached = synthetic.build_structured_model(cfg, seed=rec["seed"], exit_layer=rec["exit_layer"], dtype=torch.bfloat16,
+                                                  device="cpu", **rec.get("knobs", {}))
+        if rec["shape"] == "llama2-7B":
+            _STRUCT_CPU_CACHE[key] = cached
     if device != "cpu":
-        model = model.to(device)
-    return model
+        program = getattr(cached, "struct_program", None)
+        model = copy.deepcopy(cached).to(device) if key in _STRUCT_CPU_CACHE else cached.to(device)
+        if program is not None:
+            model.struct_program = program
+        return model
+    return copy.deepcopy(cached) if key in _STRUCT_CPU_CACHE else cached
 
 
 def bf16_ulp(value):
