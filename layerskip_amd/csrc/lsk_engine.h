@@ -97,7 +97,8 @@ int lsk_embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, elem_t* dst,
 // decoder layers [lb, le) in place over m <= 16 rows of `x` (positions *base_ptr + pos_off + i)
 int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st);
 // final norm + lm_head + argmax over rows of x; tokens land in tokens_dev[0..m); embed_dst: the chosen token's embedding row
+// kv_add > 0: the argmax launch also advances the verified context length by kv_add (device counter and host mirror)
 int lsk_run_head_dev(lsk_engine* e, const elem_t* x, int m, float* logits, int ld_logits, int* tokens_dev, hipStream_t st,
-                     elem_t* embed_dst = nullptr);
+                     elem_t* embed_dst = nullptr, int kv_add = 0);
 // rows [0, n) of the bulk buffer through layers [lb, le)
 int lsk_run_bulk_dev(lsk_engine* e, int n, const int* base_ptr, int lb, int le, hipStream_t st);

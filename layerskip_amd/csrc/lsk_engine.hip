@@ -486,7 +486,7 @@ int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int
 
 // final norm + lm_head + argmax over rows of x; tokens land in tokens_dev[0..m)
 int lsk_run_head_dev(lsk_engine* e, const elem_t* x, int m, float* logits, int ld_logits, int* tokens_dev, hipStream_t st,
-                     elem_t* embed_dst) {
+                     elem_t* embed_dst, int kv_add) {
     const lsk_config& c = e->cfg;
     if (!e->lm_head || !e->final_norm) return lsk_fail("the final norm / lm_head are not bound on this engine (a middle pipeline rank runs no head)");
     if (embed_dst != nullptr && !e->embed) return lsk_fail("the embedding is not bound on this engine");
@@ -500,10 +500,14 @@ int lsk_run_head_dev(lsk_engine* e, const elem_t* x, int m, float* logits, int l
     LSK_TRY(profile_pair(e, LSK_PROF_HEAD, m, (double)p.wp_bytes, &ea, &eb));
     LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, e->target_wgs, st, &grid, ea, eb)));
     if (grid > e->max_parts) return lsk_fail("internal: head grid %d > max_parts %d", grid, e->max_parts);
-    if (tokens_dev == nullptr) return 0;                         // sample=True: the logits rows are what the caller wants, nobody reads an argmax
+    if (tokens_dev == nullptr) {                                 // sample=True: the logits rows are what the caller wants, nobody reads an argmax
+        if (kv_add) return lsk_fail("internal: a head without an argmax launch cannot advance the context");
+        return 0;
+    }
     hipLaunchKernelGGL(lsk_argmax_finalize_kernel, dim3(m), dim3(embed_dst ? 256 : 64), 0, st, e->part_val, e->part_idx, grid, m, tokens_dev,
-                       e->embed, e->cfg.hidden, e->cfg.vocab, embed_dst);
+                       e->embed, e->cfg.hidden, e->cfg.vocab, embed_dst, kv_add ? e->state : nullptr, kv_add);
     HIP_OK(hipGetLastError());
+    e->kv_len_host += kv_add;
     return 0;
 }
 

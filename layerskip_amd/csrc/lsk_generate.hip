@@ -372,8 +372,7 @@ extern "C" int lsk_ar_step(lsk_engine* e, const int32_t* input_ids, int32_t n_id
     }
     LSK_TRY(lsk_embed_rows_dev(e, e->row_tokens, 1, e->hrow, st));
     LSK_TRY(lsk_run_layers_dev(e, e->hrow, 1, kvp, P - 1, 0, layer_end, st));
-    LSK_TRY(lsk_run_head_dev(e, e->hrow, 1, nullptr, 0, e->verified, st));
-    LSK_TRY(lsk_set_kv_len_dev(e, P, true, st));
+    LSK_TRY(lsk_run_head_dev(e, e->hrow, 1, nullptr, 0, e->verified, st, nullptr, P));      // argmax + the context advances by the P new tokens
     HIP_OK(hipMemcpyAsync(next_token, e->verified, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     return 0;
@@ -416,8 +415,8 @@ extern "C" int lsk_ar_generate(lsk_engine* e, const int32_t* input_ids, int32_t 
         for (int i = 0; i < blk; ++i) {
             // the row at hrow[0] is the embedding of the current input token; it sits at position kv_len + (P-1 | 0)
             LSK_TRY(lsk_run_layers_dev(e, e->hrow, 1, kvp, first ? P - 1 : 0, 0, layer_end, st));
-            LSK_TRY(lsk_run_head_dev(e, e->hrow, 1, nullptr, 0, e->verified + i, st, e->hrow));   // next token -> hrow[0]
-            LSK_TRY(lsk_set_kv_len_dev(e, first ? P : 1, true, st));
+            // next token -> hrow[0]; the same launch advances the context (the one-thread launch that did only that cost a dispatch per token)
+            LSK_TRY(lsk_run_head_dev(e, e->hrow, 1, nullptr, 0, e->verified + i, st, e->hrow, first ? P : 1));
             first = 0;
         }
         HIP_OK(hipMemcpyAsync(e->host_result, e->verified, sizeof(int) * blk, hipMemcpyDeviceToHost, st));

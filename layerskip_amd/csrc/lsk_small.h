@@ -44,13 +44,15 @@ __global__ void lsk_embed_kernel(const elem_t* __restrict__ embed, const int* __
 }
 
 // final argmax over the per-workgroup partials of the lm_head kernel (lowest index wins ties); optionally the
-// embedding row of the chosen token is copied straight into the next draft row (saves one launch per draft)
+// embedding row of the chosen token is copied straight into the next draft row (saves one launch per draft), and optionally the
+// verified context length advances by kv_add (the autoregressive loop: saves the one-thread launch that did only that, per token)
 __global__ void lsk_argmax_finalize_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int n_parts,
                                            int m, int* __restrict__ tokens_out, const elem_t* __restrict__ embed, int hidden,
-                                           int vocab, elem_t* __restrict__ embed_dst) {
+                                           int vocab, elem_t* __restrict__ embed_dst, StepState* st, int kv_add) {
     __shared__ int s_tok;
     const int row = blockIdx.x;
     if (row >= m) return;
+    if (st != nullptr && row == 0 && threadIdx.x == 0) st->kv_len += kv_add;     // nothing in this launch reads it
     if (threadIdx.x < 64) {
         float v = -INFINITY;
         int idx = 0x7fffffff;

@@ -144,7 +144,7 @@ extern "C" int lsk_test_head(const void* x, int32_t m, int32_t hidden, const voi
     hipStream_t st = (hipStream_t)stream;
     LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, target_wgs > 0 ? target_wgs : 256, st, &grid)));
     hipLaunchKernelGGL(lsk_argmax_finalize_kernel, dim3(m), dim3(64), 0, st, p.part_val, p.part_idx, grid, m, tokens_out_dev,
-                       (const elem_t*)nullptr, hidden, vocab, (elem_t*)nullptr);
+                       (const elem_t*)nullptr, hidden, vocab, (elem_t*)nullptr, (StepState*)nullptr, 0);
     HIP_OK(hipGetLastError());
     return 0;
 }
