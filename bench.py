@@ -385,6 +385,8 @@ def prefill_leg(args, cfg, engine):
     between two device synchronisations, against the dense bf16 MFMA peak (north_star: "MFMA utilisation against gfx950 peak")."""
     from layerskip_amd.engine import BUF_BULK
     rows = args.prompt_len - 1
+    if rows < 1:
+        return None                     # --prompt-len 1: no prompt row goes through the prefill kernels (lsk_run_bulk refuses 0 rows)
     H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
     hd = getattr(cfg, "head_dim", None) or H // cfg.num_attention_heads
     nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads

@@ -3,7 +3,7 @@
  *
  * This is the drop-in boundary for the reference's hot path (facebookresearch/LayerSkip,
  * self_speculation/):  the Python `GenerationStrategy` subclass in
- * layerskip_amd/self_speculation/ binds these symbols with ctypes exactly where the reference
+ * layerskip_amd/hip_strategies.py (through layerskip_amd/engine.py and layerskip_amd/_lib.py) binds these symbols with ctypes exactly where the reference
  * calls into HF transformers / torch ATen.  Every entry point that replaces a reference function
  * cites it (file:line relative to the reference tree).  No torch types cross this boundary:
  * only raw device pointers (`void*` obtained from `tensor.data_ptr()`), host pointers, sizes and
@@ -33,15 +33,17 @@
 extern "C" {
 #endif
 
-#define LSK_ABI_VERSION 3   /* 2: options 4 / 6 removed, draft-block / sampled / profile-table entry points added, lsk_test_* moved to
+#define LSK_ABI_VERSION 4   /* 2: options 4 / 6 removed, draft-block / sampled / profile-table entry points added, lsk_test_* moved to
                              liblayerskip_hip_test.so (include/layerskip_hip_test.h), lsk_engine_weights_checksum added
                              3: sample=True on the layer pipeline (lsk_draft_block_sampled, lsk_pipeline_pack_sampled,
                              lsk_pipeline_tail_sampled, lsk_pipeline_residual, lsk_pipeline_result_words); message header 24 -> 40 words;
                              option 8 (the resident one-row grid) and lsk_engine_device_errors retired (profiles/r05_chain_resident_grid_retired.patch);
-                             lsk_engine_set_globals accepts NULL embed / final_norm / lm_head (middle pipeline ranks) */
+                             lsk_engine_set_globals accepts NULL embed / final_norm / lm_head (middle pipeline ranks)
+                             4: LSK_MAX_EOS 8 -> 1024 (the reference folds any number of stop_token_ids into the eos list, generator_base.py:106;
+                             the workspace's eos region grew with it); vocabularies that are not a multiple of 16 documented as supported */
 #define LSK_MAX_ROWS 16
 #define LSK_MAX_SPEC 15   /* num_speculations handled by one fused step (rows = spec + 1) */
-#define LSK_MAX_EOS 8
+#define LSK_MAX_EOS 1024   /* eos + stop token ids of one generation (generator_base.py:106); ids outside the vocabulary are dropped by the host */
 
 /* Model / engine geometry.  Mirrors the fields of transformers.LlamaConfig the reference's
  * forward functions depend on (llama_model_utils.py:155-391 via modeling_llama.py). */
@@ -52,7 +54,7 @@ typedef struct lsk_config {
     int32_t n_heads;
     int32_t n_kv_heads;
     int32_t head_dim;         /* 64 or 128 */
-    int32_t vocab;            /* V, multiple of 16 */
+    int32_t vocab;            /* V; any size (the last 16-row tile of the packed lm_head is zero-padded, its columns never win an argmax) */
     float   rms_eps;
     int32_t max_ctx;          /* tokens the KV pool can hold (multiple of page_size) */
     int32_t page_size;        /* tokens per KV page: 128 */

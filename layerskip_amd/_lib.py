@@ -11,8 +11,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_uint64, c_vo
 
 LSK_MAX_ROWS = 16
 LSK_MAX_SPEC = 15
-LSK_MAX_EOS = 8
-LSK_ABI_VERSION = 3
+LSK_MAX_EOS = 1024
+LSK_ABI_VERSION = 4
 LSK_OPT_BIG_THRESHOLD = 1
 LSK_OPT_TARGET_WGS = 2
 LSK_OPT_FUSED_ATTN = 3

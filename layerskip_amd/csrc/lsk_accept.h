@@ -12,18 +12,36 @@
 #define LSK_RES_DRAFT 21
 #define LSK_RES_VERIFIED 37
 #define LSK_RES_INTS 54
+// Which lanes of ONE wave hold a token of the eos list (lane l: token d, counted only where `valid`).  The list is walked in chunks of 64
+// ids -- one coalesced load per chunk, then one lane broadcast + compare per id -- so its length only costs what it holds: the
+// reference folds ANY number of stop_token_ids into it (generator_base.py:106); LSK_MAX_EOS = 1024 here.
+__device__ __forceinline__ unsigned long long lsk_eos_ballot(int d, bool valid, const int* __restrict__ eos, int n_eos) {
+    const int lane = threadIdx.x & 63;
+    bool hit = false;
+    for (int k0 = 0; k0 < n_eos; k0 += 64) {
+        const int e = (k0 + lane < n_eos) ? eos[k0 + lane] : -1;
+        const int cnt = min(64, n_eos - k0);
+        for (int j = 0; j < cnt; ++j) hit |= (d == __shfl(e, j, 64));
+    }
+    return __ballot(valid && hit);
+}
+
+// Number of drafts that count: a drafted EOS ends the draft (SSG:146-148).  Called by every lane of one wave; lane l reads draft[l].
+__device__ __forceinline__ int lsk_drafts_until_eos(const int* __restrict__ draft, int num_drafts, const int* __restrict__ eos, int n_eos) {
+    const int lane = threadIdx.x & 63;
+    const int d = lane < num_drafts ? draft[lane] : -1;
+    const unsigned long long eos_mask = lsk_eos_ballot(d, lane < num_drafts, eos, n_eos);
+    return eos_mask ? min(num_drafts, (int)__ffsll((long long)eos_mask)) : num_drafts;
+}
+
 __device__ __forceinline__ void lsk_accept_body(const int* __restrict__ draft, int* __restrict__ next_input, const int* __restrict__ verified,
                                                 int num_drafts, const int* __restrict__ eos, int n_eos, int prompt_len, StepState* st,
                                                 int* __restrict__ result) {
     const int lane = threadIdx.x;
     int d = -1, v = -2;
-    bool is_eos = false;
-    if (lane < num_drafts) {
-        d = draft[lane];
-        for (int i = 0; i < n_eos; ++i) is_eos |= (d == eos[i]);
-    }
+    if (lane < num_drafts) d = draft[lane];
     if (lane <= num_drafts) v = verified[lane];
-    const unsigned long long eos_mask = __ballot(is_eos);
+    const unsigned long long eos_mask = lsk_eos_ballot(d, lane < num_drafts, eos, n_eos);
     const int td = eos_mask ? min(num_drafts, (int)__ffsll((long long)eos_mask)) : num_drafts;
     const unsigned long long mism = __ballot(lane < td && d != v) | (1ull << td);
     const int n = (int)__ffsll((long long)mism) - 1;
@@ -66,7 +84,8 @@ __global__ void lsk_accept_kernel(int* __restrict__ draft, const int* __restrict
 #define LSK_HDR_OFF_LO 22      // the step's Philox offset (counter words 2-3) as rank 0 used it for the drafts: the last rank, which counts
 #define LSK_HDR_OFF_HI 23      //   steps on its own, refuses the block when the two disagree (a protocol out of step must not pass as a draw)
 #define LSK_HDR_PDRAFT 24      // [16] fp32 bit patterns: p_i(x_i), the warped draft probability of draft token i (SSG:194's denominator)
-#define LSK_HDR_WORDS 40
+// LSK_HDR_WORDS (40): lsk_common.h -- lsk_check_cfg (lsk_engine.hip) refuses a hidden size whose row cannot hold the header
+static_assert(LSK_HDR_PDRAFT + LSK_ROWS == LSK_HDR_WORDS, "header layout");
 #define LSK_HDR_HOST_WORDS 24  // what a host reads back of a header (magic .. the Philox offset)
 #define LSK_HDR_MAGIC_VALUE 0x4c534b31
 

@@ -27,6 +27,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LSK_KC_ELEMS 4096
 #define LSK_SPW 16             // k-steps per wave per (tile, chunk) unit = depth of the weight ring
 #define LSK_ROWS 16
+#define LSK_HDR_WORDS 40           // int32 words of the layer pipeline's message header (layout: lsk_accept.h); must fit ONE hidden row
 #define LSK_ATTN_PAGE 128          // KV page size == keys per decode-attention workgroup
 #define LSK_PAGE_SHIFT 7           // log2(LSK_ATTN_PAGE): lsk_check_cfg refuses any other page size, so position -> (page, slot) is a shift and a mask in
                                    // the prefill kernel (a division by the runtime page_size field is a ~35-instruction VALU sequence per row and lane:

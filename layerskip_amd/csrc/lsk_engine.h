@@ -25,7 +25,7 @@ struct lsk_engine {
     bool block_table_identity = true;   // host mirror: logical page i is physical page i (the attention kernel then needs no table read)
     int* row_tokens = nullptr;    // [17] token of each step row (row 0 = input token, row j = draft j)
     int* verified = nullptr;      // [17]
-    int* eos = nullptr;           // [8]
+    int* eos = nullptr;           // [LSK_MAX_EOS]
     int* result = nullptr;        // [4 + 17]
     int* bulk_ids = nullptr;      // [max_prompt]
     float* part_val = nullptr;    // [max_parts][16]

@@ -51,6 +51,11 @@ int lsk_check_cfg(const lsk_config* c) {
     if (c->page_size != LSK_ATTN_PAGE) return lsk_fail("page_size must be %d", LSK_ATTN_PAGE);
     if (c->max_ctx <= 0 || c->max_ctx % c->page_size) return lsk_fail("max_ctx must be a positive multiple of page_size");
     if (c->num_layers <= 0 || c->vocab <= 0 || c->max_prompt < 0) return lsk_fail("bad geometry");
+    // row 0 of the layer pipeline's message buffer is the header: LSK_HDR_WORDS int32 words must fit one hidden row, or the words of
+    // drafts 8..15 would overlap message row 1, which other workgroups of lsk_pipeline_pack_kernel write concurrently
+    if ((size_t)c->hidden * sizeof(elem_t) < (size_t)LSK_HDR_WORDS * sizeof(int))
+        return lsk_fail("hidden %d too small: a hidden row must hold the %d-word pipeline header (hidden >= %d)", c->hidden, LSK_HDR_WORDS,
+                        (int)(LSK_HDR_WORDS * sizeof(int) / sizeof(elem_t)));
     return 0;
 }
 
@@ -66,7 +71,7 @@ static WsLayout ws_layout(const lsk_config* c) {
     L.block_table = take(sizeof(int) * (size_t)L.n_pages);
     L.row_tokens = take(sizeof(int) * 32);
     L.verified = take(sizeof(int) * 32);
-    L.eos = take(sizeof(int) * 16);
+    L.eos = take(sizeof(int) * LSK_MAX_EOS);
     L.result = take(sizeof(int) * 128);
     L.bulk_ids = take(sizeof(int) * (size_t)(c->max_prompt + 16));
     L.part_val = take(sizeof(float) * 16 * (size_t)L.max_parts);

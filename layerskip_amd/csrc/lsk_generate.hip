@@ -58,6 +58,9 @@ static int sample_sequence_status(lsk_engine* e, hipStream_t st) {
 
 static int launch_sample(lsk_engine* e, const float* logits, int ld, int m, float temperature, int top_k, float top_p, uint64_t seed,
                          uint64_t offset, int tag0, int* tokens_dev, float* probs, elem_t* embed_dst, hipStream_t st) {
+    // (lsk_engine_set_globals accepts a NULL embedding -- a pipeline rank that embeds nothing; a draw that is to leave its token's embedding
+    // row behind needs one)
+    if (embed_dst != nullptr && !e->embed) return lsk_fail("sample=True: the embedding is not bound on this engine (only rank 0 of a pipeline drafts)");
     SampleParams sp{};
     sp.logits = logits; sp.ld = ld; sp.vocab = e->cfg.vocab; sp.inv_temperature = 1.0f / temperature;
     sp.top_k = top_k; sp.top_p = top_p;

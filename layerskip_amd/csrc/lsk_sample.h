@@ -25,6 +25,7 @@
 // compared draw for draw, and restates the reference's warping so that the kept sets can be compared with HF's.
 #pragma once
 #include "lsk_common.h"
+#include "lsk_accept.h"      // result-block layout (LSK_RES_*), the header words, lsk_drafts_until_eos
 
 #define LSK_SAMPLE_THREADS 1024
 #define LSK_SAMPLE_WAVES 16
@@ -911,11 +912,10 @@ __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_accept_sampled_kernel(
     __shared__ int redi[LSK_SAMPLE_WAVES];
     __shared__ int s_td, s_n;
     const int tid = threadIdx.x;
+    int td_w0 = 0;
+    if (tid < 64) td_w0 = lsk_drafts_until_eos(p.draft, p.num_drafts, p.eos, p.n_eos);   // wave 0: a drafted EOS ends the draft (SSG:146-148)
     if (tid == 0) {
-        int td = p.num_drafts;
-        for (int i = 0; i < p.num_drafts && td == p.num_drafts; ++i)
-            for (int k = 0; k < p.n_eos; ++k)
-                if (p.draft[i] == p.eos[k]) { td = i + 1; break; }       // a drafted EOS ends the draft (SSG:146-148)
+        const int td = td_w0;
         int n = 0;
         for (int i = 0; i < td; ++i) {
             const int tok = p.draft[i];
@@ -992,14 +992,13 @@ __global__ __launch_bounds__(LSK_SAMPLE_THREADS) void lsk_pipeline_accept_sample
     __shared__ int s_n;
     const int tid = threadIdx.x;
     const int* hdr = (const int*)p.msg;
+    const int num_drafts = min(max(hdr[LSK_HDR_ROWS], 1), LSK_ROWS) - 1;
+    const int* draft = hdr + LSK_HDR_DRAFTS;
+    int td_w0 = 0;
+    if (tid < 64) td_w0 = lsk_drafts_until_eos(draft, num_drafts, p.eos, p.n_eos);      // wave 0: a drafted EOS ends the draft (SSG:146-148)
     if (tid == 0) {
-        const int num_drafts = min(max(hdr[LSK_HDR_ROWS], 1), LSK_ROWS) - 1;
-        const int* draft = hdr + LSK_HDR_DRAFTS;
         const bool out_of_step = hdr[LSK_HDR_MODE] != 1 || (unsigned int)hdr[LSK_HDR_OFF_LO] != p.off_lo || (unsigned int)hdr[LSK_HDR_OFF_HI] != p.off_hi;
-        int td = num_drafts;
-        for (int i = 0; i < num_drafts && td == num_drafts; ++i)
-            for (int k = 0; k < p.n_eos; ++k)
-                if (draft[i] == p.eos[k]) { td = i + 1; break; }       // a drafted EOS ends the draft (SSG:146-148)
+        const int td = td_w0;
         int n = 0;
         for (int i = 0; i < td; ++i) {
             const float q = p.p_verify[(size_t)i * p.ld + draft[i]];

@@ -54,11 +54,13 @@ class HipEngine:
         _lib.check(status, self.lib)
 
     def _eos_array(self, eos_token_ids: Sequence[int]):
-        """Ids outside the vocabulary can never be produced and are dropped; more than LSK_MAX_EOS real ids is an
-        error (never a silent truncation: the device-side draft cut and the host-side output cut must agree)."""
-        eos = [int(t) for t in eos_token_ids if t is not None and 0 <= int(t) < self.vocab]     # None: a tokenizer without eos
+        """The eos list as the device sees it: ids outside the vocabulary can never be produced and are dropped, repeats are dropped
+        (first occurrence kept: the list ORDER decides which id truncates the output, SSG:82-91).  The reference folds any number of
+        `stop_token_ids` into this list (generator_base.py:106); the device list holds LSK_MAX_EOS = 1024 -- more than that is an error,
+        never a silent truncation (the device-side draft cut and the host-side output cut must agree)."""
+        eos = list(dict.fromkeys(int(t) for t in eos_token_ids if t is not None and 0 <= int(t) < self.vocab))     # None: a tokenizer without eos
         if len(eos) > _lib.LSK_MAX_EOS:
-            raise _lib.LskError(f"{len(eos)} eos token ids; the engine supports at most {_lib.LSK_MAX_EOS}")
+            raise _lib.LskError(f"{len(eos)} distinct eos / stop token ids; the engine supports at most {_lib.LSK_MAX_EOS}")
         return eos, _i32_array(eos)
 
     def __init__(self, model, max_ctx: int = 2048, max_prompt: int = 1024, page_size: int = 128,
@@ -523,14 +525,18 @@ class HipEngine:
         """Final norm + lm_head logits of the listed (buffer, row_base, count) blocks -> [rows, vocab] in the model dtype (the values
         the reference's `model.lm_head` returns, LMU:273, :387): what logits processors are shown."""
         total = sum(c for _, _, c in blocks)
-        out = torch.empty(total, self.vocab, dtype=torch.float32, device=self.device)
+        # (16 rows at a time through ONE fp32 staging block straight into the model dtype: a 2 048-row prompt at V = 128 256 is 0.5 GB in
+        # bf16; the fp32 image of all rows plus a converted copy was three times that)
+        out = torch.empty(total, self.vocab, dtype=self.dtype, device=self.device)
+        stage = torch.empty(_lib.LSK_MAX_ROWS, self.vocab, dtype=torch.float32, device=self.device)
         at = 0
         for buf, base, count in blocks:
             for r0 in range(0, count, _lib.LSK_MAX_ROWS):
                 m = min(_lib.LSK_MAX_ROWS, count - r0)
-                self.run_head(buf, base + r0, m, logits=out[at:at + m], want_tokens=False)
+                self.run_head(buf, base + r0, m, logits=stage[:m], want_tokens=False)
+                out[at:at + m].copy_(stage[:m])
                 at += m
-        return out.to(self.dtype)
+        return out
 
     def header(self) -> List[int]:
         """The int32 words of the message header (synchronises: a device -> host read)."""

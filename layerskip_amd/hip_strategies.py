@@ -144,10 +144,18 @@ class HipSelfSpeculativeGenerationStrategy(GenerationStrategy):
                     generation_config.temperature, generation_config.top_k, generation_config.top_p,
                     torch.initial_seed(), self._sample_base)
                 self._sample_step += len(self.last_steps) + 1
+                self._stream_fresh = False        # the fused call consumed this generation's stream: a later stand-alone step starts its own
             else:
                 tokens, matches, drafts, self.last_steps = engine.spec_generate(
                     list(input_ids), spec, generation_config.exit_layer, eos_token_ids, generation_config.max_steps)
             return GenerationStrategyResult(predicted_tokens=tokens, acceptance_rate=matches / drafts)
+        try:
+            return self._step_loop(model, input_ids, eos_token_ids, generation_config, logits_processors, stopping_criteria, streamer)
+        finally:
+            self._stream_fresh = False            # (a generation that ran no sampled step -- max_steps = 0, an error -- must not leave the mark behind)
+
+    def _step_loop(self, model, input_ids, eos_token_ids, generation_config, logits_processors, stopping_criteria, streamer):
+        """SSG:51-99, one `single_step_speculation` call per step (streamers, stopping criteria, logits processors)."""
         past = None
         input_ids_list = list(input_ids)
         cur = torch.tensor([input_ids_list])

@@ -60,14 +60,14 @@ BUF_STEP = 0
 BUF_BULK = 1
 BUF_MSG = 2         # row 0 = header (int32 words), rows 1.. = the verify block
 _MAX_ROWS = 16
-_MAX_EOS = 8
+_MAX_EOS = 1024    # LSK_MAX_EOS (include/layerskip_hip.h): eos + stop token ids of one generation
 _RES_WORDS = 24     # of the result block: num_matches, num_drafts, next token, context length, emitted[17]
 RES_PENDING, RES_ERROR = 21, 22     # sampled result block (csrc/lsk_sample.h): residual draw pending, protocol error
 # header words (layerskip_amd/csrc/lsk_accept.h); a host reads the first HDR_WORDS back
 HDR_MAGIC, HDR_GO, HDR_P, HDR_ROWS, HDR_KV, HDR_DRAFTS, HDR_MODE, HDR_OFF_LO, HDR_OFF_HI, HDR_WORDS = 0, 1, 2, 3, 4, 5, 21, 22, 23, 24
 HDR_MAGIC_VALUE = 0x4C534B31
 MODE_GREEDY, MODE_SAMPLED, MODE_LOGITS = 0, 1, 2      # what the last rank does with a verify block
-_META_WORDS = 4 + _MAX_EOS + 6
+_META_WORDS = 4 + 7  # (P, S, max_steps, n_eos), mode, five sampling words, "prompt rows wanted"; the eos ids follow in a broadcast of their own
 
 
 @dataclass
@@ -201,24 +201,26 @@ class PipelineSpeculativeDecoder:
             dist.recv(t, src=src, group=self.group)
             self.be.write_rows(buffer, row_base, t)
 
-    def _agree(self, prompt_ids, eos_token_ids, max_steps: int, S: int, mode: int = MODE_GREEDY, sampling: Optional[Sampling] = None):
+    def _agree(self, prompt_ids, eos_token_ids, max_steps: int, S: int, mode: int = MODE_GREEDY, sampling: Optional[Sampling] = None,
+               prompt_rows: bool = False):
         """Collective set-up: rank 0's (P, S, max_steps, eos ids) reach every rank, every rank sizes its engine for the WHOLE
         generation (rank 0's optimistic continuation writes up to 2S+2 positions past the verified length; the stop message
         makes the late ranks run one block on stale rows), and all ranks learn whether all of them could."""
         be = self.be
         meta = torch.zeros(_META_WORDS, dtype=torch.int64)
+        eos: List[int] = []
         if self.rank == 0 and prompt_ids is None:
             meta[0] = -1                      # shutdown(): the serve loops of the other ranks end
         elif self.rank == 0:
-            eos = [int(t) for t in eos_token_ids if t is not None and 0 <= int(t) < be.vocab]
-            # (too many eos ids: the COUNT travels, so that the error below is raised on every rank through the agreement --
-            # raising here would leave the other ranks waiting in the broadcast)
+            # (the reference folds any number of stop_token_ids into this list, generator_base.py:106: the ids travel in a broadcast of their
+            # own, sized by the count in the meta words)
+            eos = list(dict.fromkeys(int(t) for t in eos_token_ids if t is not None and 0 <= int(t) < be.vocab))
             meta[:4] = torch.tensor([len(prompt_ids), S, max_steps, len(eos)])
-            meta[4:4 + min(len(eos), _MAX_EOS)] = torch.tensor(eos[:_MAX_EOS], dtype=torch.int64)
-            meta[4 + _MAX_EOS] = mode
+            meta[4] = mode
             if sampling is not None:
-                meta[5 + _MAX_EOS:] = torch.tensor([int(sampling.top_k), _u64_to_i64(sampling.seed), _u64_to_i64(sampling.offset),
-                                                    _f64_bits(sampling.temperature), _f64_bits(sampling.top_p)], dtype=torch.int64)
+                meta[5:10] = torch.tensor([int(sampling.top_k), _u64_to_i64(sampling.seed), _u64_to_i64(sampling.offset),
+                                           _f64_bits(sampling.temperature), _f64_bits(sampling.top_p)], dtype=torch.int64)
+            meta[10] = 1 if prompt_rows else 0
         if self.world > 1:
             meta = meta.to(self.dev)
             dist.broadcast(meta, src=0, group=self.group)
@@ -226,16 +228,22 @@ class PipelineSpeculativeDecoder:
         P, S, max_steps, n_eos = (int(v) for v in meta[:4].tolist())
         if P == -1:
             return None
-        eos = [int(v) for v in meta[4:4 + min(n_eos, _MAX_EOS)].tolist()]
-        tail = [int(v) for v in meta[4 + _MAX_EOS:].tolist()]
+        if self.world > 1 and n_eos > 0:
+            ids = (torch.tensor(eos, dtype=torch.int64) if self.rank == 0 else torch.zeros(n_eos, dtype=torch.int64)).to(self.dev)
+            dist.broadcast(ids, src=0, group=self.group)
+            eos = [int(v) for v in ids.cpu().tolist()]
+        tail = [int(v) for v in meta[4:].tolist()]
         mode = tail[0]
+        # logits mode: do the FIRST block's P - 1 prompt rows come back too?  Only logits processors look at them (SSG:172-173 shows them every
+        # input row); without the bit a sampled autoregressive run over a 2 048-token prompt and V = 128 256 built, sent and dropped 0.5 GB
+        self._prompt_rows = bool(tail[6])
         sampling = None
         if mode == MODE_SAMPLED:
             sampling = Sampling(_bits_f64(tail[4]), tail[1], _bits_f64(tail[5]), tail[2] & ((1 << 64) - 1), tail[3] & ((1 << 64) - 1))
         err = None
         try:
             if n_eos > _MAX_EOS:
-                raise ValueError(f"{n_eos} eos token ids; at most {_MAX_EOS}")
+                raise ValueError(f"{n_eos} distinct eos / stop token ids; at most {_MAX_EOS}")
             if S + 1 > _MAX_ROWS:
                 raise ValueError("num_speculations too large for the 16-row verify block")
             if max_steps < 1 or P < 1:
@@ -282,7 +290,7 @@ class PipelineSpeculativeDecoder:
             elif mode == MODE_LOGITS:
                 # logits processors decide on rank 0: the rows' logits go back instead of an acceptance result (LMU:386-387: the
                 # reference's forward_remainder returns logits for every input row, the prompt rows of the first step included)
-                rows = be.logits_rows(([(BUF_BULK, 0, p - 1)] if p > 1 else []) + [(BUF_MSG, 1, S + 1)])
+                rows = be.logits_rows(([(BUF_BULK, 0, p - 1)] if (p > 1 and self._prompt_rows) else []) + [(BUF_MSG, 1, S + 1)])
                 dist.send(rows if self.direct else rows.to(self.dev), dst=0, group=self.group)
             elif mode == MODE_SAMPLED:
                 res = be.pipeline_tail_sampled(S + 1, sampling.temperature, sampling.top_k, sampling.top_p, sampling.seed,
@@ -328,13 +336,13 @@ class PipelineSpeculativeDecoder:
                 sm = self._sampling
                 return be.pipeline_tail_sampled(m, sm.temperature, sm.top_k, sm.top_p, sm.seed, offset)
             if self._mode == MODE_LOGITS:
-                return be.logits_rows(([(BUF_BULK, 0, P - 1)] if P > 1 else []) + [(BUF_MSG, 1, self._S + 1)])
+                return be.logits_rows(([(BUF_BULK, 0, P - 1)] if (P > 1 and self._prompt_rows) else []) + [(BUF_MSG, 1, self._S + 1)])
             return be.pipeline_tail(m)
         if P > 1:
             self._rows_out(BUF_BULK, 0, P - 1, 1)
         self._rows_out(BUF_MSG, 0, self._S + 2, 1)
         self._inflight += 1                        # the last rank answers every message with one result block
-        self._inflight_rows = (P - 1) + self._S + 1
+        self._inflight_rows = ((P - 1) if self._prompt_rows else 0) + self._S + 1
         self._shipped += 1
         return None
 
@@ -375,7 +383,7 @@ class PipelineSpeculativeDecoder:
         p = self._P0 if self._shipped == 0 else 1
         if p > 1:
             self._rows_out(BUF_BULK, 0, p - 1, 1)
-        self._inflight_rows = (p - 1) + self._S + 1
+        self._inflight_rows = ((p - 1) if self._prompt_rows else 0) + self._S + 1
         self._rows_out(BUF_MSG, 0, self._S + 2, 1)
         self._inflight += 1
         self._answer()                             # the late ranks answer every message; this one is discarded
@@ -400,19 +408,22 @@ class PipelineSpeculativeDecoder:
             self._agree(None, [], 0, 0)
 
     def generate(self, prompt_ids: Optional[Sequence[int]], eos_token_ids: Sequence[int], max_steps: int,
-                 num_speculations: int, on_step=None, sampling: Optional[Sampling] = None, driver=None) -> Optional[PipelineResult]:
+                 num_speculations: int, on_step=None, sampling: Optional[Sampling] = None, driver=None,
+                 prompt_rows: bool = False) -> Optional[PipelineResult]:
         """Rank 0 passes the prompt and the settings; other ranks' arguments are ignored.  Mirrors SSG:32-99.
         on_step (rank 0): called after every speculation step with (draft tokens, number accepted, emitted tokens, next input
         token); a truthy return value ends the generation after that step (stopping criteria, SSG:92-95; streamers hang here too).
         sampling (rank 0): sample=True -- draws and modified rejection sampling on the devices (module docstring), draw for draw
         the one-GPU `lsk_spec_generate_sampled` under the same (seed, offset).
         driver (rank 0): logits processors -- `driver(self)` runs the generation itself on rank 0 (hip_strategies' slow path) and
-        gets every verify's logits rows through `remote_verify`; its return value is this call's.
+        gets every verify's logits rows through `remote_verify`; its return value is this call's.  prompt_rows (with a driver): the first
+        block's P - 1 prompt rows come back too -- what logits processors are shown (SSG:172-173); nobody else looks at them.
         Ranks > 0 get an empty result, or None when rank 0 shut the pipeline down instead of starting a generation."""
         if self.rank == 0 and prompt_ids is None:
             raise ValueError("rank 0 must pass the prompt")
         mode = MODE_LOGITS if driver is not None else (MODE_SAMPLED if sampling is not None else MODE_GREEDY)
-        agreed = self._agree(prompt_ids, eos_token_ids, int(max_steps), int(num_speculations), mode, sampling)
+        agreed = self._agree(prompt_ids, eos_token_ids, int(max_steps), int(num_speculations), mode, sampling,
+                             bool(prompt_rows) and driver is not None)
         if agreed is None:
             return None
         P0, S, max_steps, eos, mode, sampling = agreed
@@ -447,11 +458,11 @@ class PipelineSpeculativeDecoder:
     # ------------------------------------------------------------------ logits mode: rank 0's slow path asks for one verify at a time
     def remote_verify(self, P: int, m: int) -> torch.Tensor:
         """Rank 0, inside a `driver`: the late layers + final norm + lm_head of `forward_remainder` (LMU:364-387) over step rows
-        [0, m) and the P - 1 prompt rows in front of them, wherever those layers live -> logits [(P - 1) + m, V] in the model dtype
-        on rank 0's device (the reference returns logits for EVERY input row; processors see them all, SSG:172-173)."""
+        [0, m) and the P - 1 prompt rows in front of them, wherever those layers live -> logits [(P - 1 if prompt rows were agreed) + m, V]
+        in the model dtype on rank 0's device (the reference returns logits for EVERY input row; processors see them all, SSG:172-173)."""
         local = self._ship(P, m, self._kv_host, 0)
         rows = local if local is not None else self._answer()
-        return rows.to(self.be.device)[: P - 1 + m]
+        return rows.to(self.be.device)[: ((P - 1) if self._prompt_rows else 0) + m]
 
     def commit(self, kv: int) -> None:
         """Rank 0, inside a `driver`: the verified context length after a step (the next header carries it to the other ranks)."""

@@ -107,8 +107,8 @@ class _Rank0SlowStrategy(HipSelfSpeculativeGenerationStrategy):
     def _verify_logits(self, engine, P: int, td: int, E: int, sbuf: int, sbase: int, prompt_rows: bool) -> torch.Tensor:
         if sbuf != 0 or sbase != 0:
             raise ValueError("the layer pipeline verifies at most 16 rows per step (num_speculations <= 15)")
-        rows = self._dec.remote_verify(P, td + 1)                       # [(P - 1) + td + 1, V]
-        return (rows if prompt_rows else rows[P - 1:]).unsqueeze(0)
+        rows = self._dec.remote_verify(P, td + 1)                       # [(P - 1 if the generation asked for prompt rows) + td + 1, V]
+        return (rows if prompt_rows else rows[rows.shape[0] - (td + 1):]).unsqueeze(0)
 
     def _commit(self, engine, kv_len: int) -> None:
         self._dec.commit(kv_len)
@@ -134,7 +134,7 @@ class _Rank0SlowARStrategy(HipAutoRegressiveGenerationStrategy):
         engine.embed_rows(ids[-1:], BUF_STEP, 0)
         engine.run_layers(BUF_STEP, 0, 1, P - 1, 0, first)
         rows = self._dec.remote_verify(P, 1)
-        return (rows if prompt_rows else rows[P - 1:]).unsqueeze(0)
+        return (rows if prompt_rows else rows[rows.shape[0] - 1:]).unsqueeze(0)
 
     def _commit(self, engine, kv_len: int) -> None:
         self._dec.commit(kv_len)
@@ -232,7 +232,7 @@ class HipPipelineSelfSpeculativeGenerationStrategy(GenerationStrategy):
             def driver(_dec):
                 return inner.generate_token_ids(model, input_ids, eos, cfg, logits_processors, stopping_criteria, streamer)
 
-            return dec.generate([int(t) for t in input_ids], eos, int(cfg.max_steps), S, driver=driver)
+            return dec.generate([int(t) for t in input_ids], eos, int(cfg.max_steps), S, driver=driver, prompt_rows=True)
         sampling = None
         if generation_config.sample and not self.speculative:
             # sampled autoregressive decoding: one logits row per round trip, drawn with torch on rank 0 (the one-GPU strategy's path)

@@ -55,6 +55,12 @@ SHAPES: Dict[str, dict] = {
                      num_attention_heads=4, num_key_value_heads=2, head_dim=128,
                      vocab_size=1000, rope_theta=500000.0, max_position_embeddings=2048,
                      exit_layer=3, num_speculations=6),
+    # a checkpoint with ONE ADDED TOKEN (V = 32 001: not a multiple of 16, nor of 4 -- the last lm_head tile holds one real column,
+    # sampling rows are padded to 32 004): what `resize_token_embeddings(len(tokenizer) + 1)` produces
+    "tiny-gqa-v32001": dict(num_hidden_layers=6, hidden_size=512, intermediate_size=1408,
+                            num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+                            vocab_size=32001, rope_theta=500000.0, max_position_embeddings=2048,
+                            exit_layer=3, num_speculations=6),
     "tiny-d64": dict(num_hidden_layers=4, hidden_size=256, intermediate_size=1024,
                      num_attention_heads=4, num_key_value_heads=2, head_dim=64,
                      vocab_size=768, rope_theta=500000.0, tie_word_embeddings=True,

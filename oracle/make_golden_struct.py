@@ -55,6 +55,7 @@ class StructCase:
     fp32: bool = True           # also record the reference's fp32 run (small shapes)
     eos_from: Optional[str] = None   # derive an EOS case from this base case
     eos_index: int = 0
+    eos_pad: int = 0            # ids that never occur in the base case's output, listed IN FRONT of the eos id that does
     knobs: dict = dataclasses.field(default_factory=dict)
 
 
@@ -84,6 +85,16 @@ CASES = {
     "slice70b": StructCase("slice-70B", seed=0, prompt_len=40, max_steps=40, fp32=False),
     # BASELINE config #4 at FULL size: llama2-13B (40 layers, H = 5120), exit_layer 10, 8 speculations (9-row verify blocks)
     "full13b": StructCase("llama2-13B", seed=0, prompt_len=64, max_steps=48, fp32=False),
+    # the context limits the reference actually reaches (LMU:45-59: a dense [1,1,M,C+M] mask up to max_position_embeddings; llama2 =
+    # 4096): a 3968-token prompt = 31 KV pages, the generation crosses into the 32nd -- the >= 3-batch page combine of the decode
+    # attention, the ~4k-row prefill GEMMs / flash attention and a 32-entry block table against the unmodified reference
+    "slice7b_ctx4k": StructCase("slice-7B", seed=0, prompt_len=3968, max_steps=40),
+    "slice8b_ctx4k": StructCase("slice-8B", seed=0, prompt_len=3968, max_steps=40, fp32=False),
+    # a vocabulary with one added token: V = 32 001 (not a multiple of 16: the ragged last lm_head tile; LlamaConfig of a checkpoint after
+    # `resize_token_embeddings(len(tokenizer) + 1)`)
+    "tiny_gqa_v32001": StructCase("tiny-gqa-v32001", seed=5, prompt_len=21, max_steps=40),
+    # 12 eos / stop ids (the reference folds any number of stop_token_ids into the list, generator_base.py:106), the one that occurs LAST
+    "tiny_gqa_eos12": StructCase("tiny-gqa", seed=0, prompt_len=37, max_steps=48, eos_from="tiny_gqa", eos_index=14, eos_pad=11),
     "tiny_gqa_eos": StructCase("tiny-gqa", seed=0, prompt_len=37, max_steps=48, eos_from="tiny_gqa", eos_index=9),
     "tiny_mha_eos": StructCase("tiny-mha", seed=2, prompt_len=24, max_steps=48, eos_from="tiny_mha", eos_index=5),
 }
@@ -264,6 +275,10 @@ def main():
                 toks = json.load(f)[LOW_DTYPE[0]]["spec_tokens"]
             k = next(i for i in range(case.eos_index, len(toks)) if toks[i] not in toks[:i])
             eos = [toks[k]]
+            if case.eos_pad:
+                vocab = synthetic.make_config(case.shape).vocab_size
+                pad = [t for t in range(vocab - 1, -1, -1) if t not in toks][: case.eos_pad]
+                eos = pad + eos
         rec = build_case(ref, name, case, eos)
         path = os.path.join(OUT_DIR, name + ".json")
         if args.check:

@@ -113,6 +113,13 @@ def test_skinny_gemm_row_invariance(gpu_device):
     ([5, 2, 7, 8], [5, 2, 7, 8, 1], [2], (2, 2)),     # drafted EOS ends the draft (SSG:146-148)
     ([5, 2, 7, 8], [9, 2, 7, 8, 1], [2, 11], (0, 2)),
     (list(range(15)), list(range(15)) + [99], [], (15, 15)),
+    # the reference folds any number of stop_token_ids into the eos list (generator_base.py:106): 12 ids, the hit in the last place;
+    # 70 and 1024 ids (more than one 64-id chunk of the ballot scan), the hit in the second / last chunk
+    ([5, 6, 7, 8], [5, 6, 7, 8, 1], [100 + i for i in range(11)] + [7], (3, 3)),
+    ([5, 6, 7, 8], [5, 9, 7, 8, 1], [100 + i for i in range(11)] + [7], (1, 3)),
+    ([5, 6, 7, 8], [5, 6, 7, 8, 1], [100 + i for i in range(69)] + [8], (4, 4)),
+    ([5, 6, 7, 8, 9, 10], [5, 6, 7, 8, 9, 10, 1], [100 + i for i in range(1023)] + [6], (2, 2)),
+    ([5, 6, 7, 8], [5, 6, 7, 8, 1], [100 + i for i in range(1024)], (4, 4)),
 ])
 def test_accept_kernel(gpu_device, drafts, verified, eos, expect):
     lib, L = _lib()

@@ -219,6 +219,127 @@ def test_llama2_13b_at_full_size_on_two_pipeline_ranks_equals_one_engine(gpu_dev
     assert all(td <= S for td, _ in want_steps) and max(td for td, _ in want_steps) == S        # 9-row verify blocks
 
 
+def _fullsize_both_worker(rank, world, port, queue, model_name, prompt_len, max_steps):
+    """`_fullsize_worker` for a checkpoint whose build dominates: ONE model / engine per rank, a greedy generation and then a sampled one
+    through the same decoder (the serve loop of the late ranks takes the mode from each generation's set-up broadcast)."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    import datetime
+    one_per_gpu = torch.cuda.device_count() >= world
+    dev = torch.device("cuda", rank if one_per_gpu else 0)
+    torch.cuda.set_device(dev)
+    if one_per_gpu:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(minutes=15))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=15))
+    try:
+        from layerskip_amd import synthetic
+        from layerskip_amd.engine import HipEngine
+        from layerskip_amd.pipeline import PipelineSpeculativeDecoder, Sampling, plan_partition
+        cfg = synthetic.make_config(model_name)
+        E, S = synthetic.default_exit_layer(model_name), synthetic.default_num_speculations(model_name)
+        part = plan_partition(cfg.num_hidden_layers, E, world, balance="memory")          # SURVEY 8e: [0, 12) + 7 x 9..10 at 70B / 8
+        t0 = time.time()
+        model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=0.03, dtype=torch.bfloat16, device=dev, gen_device=dev,
+                                      layer_range=part[rank])
+        eng = HipEngine(model, max_ctx=prompt_len + max_steps + 2 * S + 32, max_prompt=prompt_len, layer_range=part[rank], release_weights=True)
+        torch.cuda.synchronize()
+        build_s = time.time() - t0
+        dec = PipelineSpeculativeDecoder(eng, rank, world, part, E, comm_device=dev if one_per_gpu else torch.device("cpu"))
+        dec.warm_transport()
+        prompt = synthetic.make_prompt(cfg.vocab_size, prompt_len, 0) if rank == 0 else None
+        runs = []
+        for sampled in (False, True):
+            sm = Sampling(**SAMPLING) if (sampled and rank == 0) else None
+            dist.barrier()
+            t0 = time.perf_counter()
+            res = dec.generate(prompt, [cfg.vocab_size], max_steps, S, sampling=sm)
+            runs.append({"tokens": res.predicted_tokens, "steps": [list(t) for t in res.steps], "seconds": time.perf_counter() - t0})
+        stats = [None] * world
+        dist.all_gather_object(stats, dict(dec.stats(), build_s=round(build_s, 2), packed_gb=round(sum(
+            t.numel() for pk in eng._packed if pk is not None for t in pk[:4]) / 2 ** 30, 2)))
+        if rank == 0:
+            queue.put((runs, [list(p) for p in part], stats, "nccl" if one_per_gpu else "gloo (ranks share device 0)"))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_llama2_70b_at_full_size_on_eight_pipeline_ranks_equals_one_engine(gpu_device):
+    """BASELINE config #5 (llama2-70B, exit_layer 12, 12 speculations -- 13-row verify blocks -- on 8 ranks: [0, 12) + 7 x 9..10 layers;
+    the reference runs it through `device_map="auto"`, generate.py:59-64, with its default sample=True, generator_base.py:39) at FULL
+    size: 96 new tokens of a random-init checkpoint whose drafts ARE rejected, greedy AND sampled, ids and per-step (drafts, matches)
+    traces identical to ONE engine holding all 80 layers.  Seven of the eight ranks hold neither the embedding's consumer nor a head; the
+    sampled protocol's q_n row crosses them.  The evidence block goes to gpurun_out/ (copied to profiles/r06_pp_70B_8ranks_one_gpu.json)."""
+    import json
+    import time
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2 ** 30:
+        pytest.skip("needs 150 GB of free HBM (8 x 17-22 GB of packed layer ranges, then 140 GB for the one-engine run)")
+    from layerskip_amd import synthetic
+    from layerskip_amd.engine import HipEngine
+    name, prompt_len, max_steps, world = "llama2-70B", 96, 96, 8
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    t_spawn = time.time()
+    procs = [ctx.Process(target=_fullsize_both_worker, args=(r, world, port, queue, name, prompt_len, max_steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    runs, part, stats, transport = queue.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    pipeline_wall_s = time.time() - t_spawn
+    assert part[0] == [0, 12] and len(part) == 8 and part[-1][1] == 80 and all(9 <= b - a <= 10 for a, b in part[1:])
+    cfg = synthetic.make_config(name)
+    E, S = synthetic.default_exit_layer(name), synthetic.default_num_speculations(name)
+    assert (E, S) == (12, 12)
+    t0 = time.time()
+    model = synthetic.build_model(cfg, seed=0, exit_layer=E, late_damping=0.03, dtype=torch.bfloat16, device=gpu_device, gen_device=gpu_device)
+    eng = HipEngine(model, max_ctx=prompt_len + max_steps + 2 * S + 32, max_prompt=prompt_len, release_weights=True)
+    torch.cuda.synchronize()
+    one_build_s = time.time() - t0
+    prompt = synthetic.make_prompt(cfg.vocab_size, prompt_len, 0)
+    t0 = time.perf_counter()
+    want_g, _, _, steps_g = eng.spec_generate(prompt, S, E, [cfg.vocab_size], max_steps)
+    one_greedy_s = time.perf_counter() - t0
+    sm = SAMPLING
+    t0 = time.perf_counter()
+    want_s, _, _, steps_s = eng.spec_generate_sampled(prompt, S, E, [cfg.vocab_size], max_steps, sm["temperature"], sm["top_k"], sm["top_p"],
+                                                      sm["seed"], sm["offset"])
+    one_sampled_s = time.perf_counter() - t0
+    eng.close()
+    del eng, model
+    torch.cuda.empty_cache()
+    for run, want, want_steps, label in ((runs[0], want_g, steps_g, "greedy"), (runs[1], want_s, steps_s, "sampled")):
+        assert len(want) == max_steps and run["tokens"] == want, label
+        assert [tuple(t) for t in run["steps"]] == [tuple(t) for t in want_steps], label
+        assert any(n < td for td, n in want_steps), f"{label}: the run must contain rejected drafts"
+        assert max(td for td, _ in want_steps) == S, f"{label}: 13-row verify blocks"
+    assert all(st["hops"] == len(steps_g) + 1 + len(steps_s) + 1 for st in stats[1:])       # every late rank served every block + the two stop messages
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "r06_pp_70B_8ranks_one_gpu.json"), "w") as f:
+            json.dump({"model": name, "world": world, "partition": part, "transport": transport, "prompt_len": prompt_len, "new_tokens": max_steps,
+                       "exit_layer": E, "num_speculations": S,
+                       "greedy": {"identical_to_one_engine": True, "steps": len(steps_g), "acceptance": round(sum(n for _, n in steps_g) / sum(td for td, _ in steps_g), 4),
+                                  "pipeline_tokens_per_s": round(max_steps / runs[0]["seconds"], 1), "one_engine_tokens_per_s": round(max_steps / one_greedy_s, 1)},
+                       "sampled": {"identical_to_one_engine": True, "steps": len(steps_s), "acceptance": round(sum(n for _, n in steps_s) / sum(td for td, _ in steps_s), 4),
+                                   "sampling": {k: SAMPLING[k] for k in ("temperature", "top_k", "top_p")},
+                                   "pipeline_tokens_per_s": round(max_steps / runs[1]["seconds"], 1), "one_engine_tokens_per_s": round(max_steps / one_sampled_s, 1)},
+                       "per_rank": stats, "pipeline_wall_s_incl_spawn_and_build": round(pipeline_wall_s, 1), "one_engine_build_s": round(one_build_s, 1),
+                       "note": "tests/test_gpu_pipeline.py::test_llama2_70b_at_full_size_on_eight_pipeline_ranks_equals_one_engine"}, f, indent=1)
+    except OSError:
+        pass
+
+
 def _nccl_worker(rank, world, port, queue):
     """One rank per DEVICE, backend nccl (= RCCL): rows go straight from / into the engines' message buffers over xGMI."""
     import sys

@@ -208,14 +208,16 @@ def test_graph_replayed_steps_give_the_same_generation(gpu_device, name):
 
 
 @pytest.mark.parametrize("mode", ["fused", "stepwise", "graph", "pipeline"])
-@pytest.mark.parametrize("name", ["tiny_gqa", "tiny_gqa_long", "tiny_mha_spec6", "slice7b", "full7b_512"])
+@pytest.mark.parametrize("name", ["tiny_gqa", "tiny_gqa_long", "tiny_mha_spec6", "slice7b", "full7b_512", "slice7b_ctx4k", "slice8b_ctx4k"])
 def test_logits_on_the_live_kv_state_after_rollbacks(gpu_device, name, mode):
     """Token equality cannot see a KV / RoPE / rollback error on these checkpoints (the next token is a wide-margin lookup on
     the current one), so the CONTEXT-sensitive quantity is checked on the state a speculative generation leaves behind: after
     a generation full of rejected drafts (KV slots written, rolled back, overwritten), ONE more row -- the last emitted token
     at the next position, over the live KV pool -- must give the reference's teacher-forced logits of that position.
     Modes: the fused one-call generation (steps pipelined on the stream), one call per step, hipGraph-replayed steps, and the
-    layer pipeline's protocol (one rank: draft blocks + optimistic bookkeeping through the building-block API)."""
+    layer pipeline's protocol (one rank: draft blocks + optimistic bookkeeping through the building-block API).
+    The `_ctx4k` fixtures put this at the context limit the reference reaches (LMU:45-59; llama2: 4096): a 3968-token prompt = 31 KV pages
+    through the ~4k-row prefill GEMMs / flash attention, the live row attends over 32 pages (four batches of the last arriver's page combine)."""
     from layerskip_amd import _lib
     from layerskip_amd.engine import BUF_STEP, get_engine
     from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy

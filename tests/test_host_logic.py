@@ -155,6 +155,13 @@ def test_eos_list_is_never_silently_truncated():
     eos, arr = eng._eos_array([2, 1000, -1, 7])
     assert eos == [2, 7] and list(arr)[:2] == [2, 7]         # ids outside the vocabulary can never be produced
     assert eng._eos_array([])[0] == []
+    # the reference folds any number of stop_token_ids into the list (generator_base.py:106): repeats collapse (first occurrence kept,
+    # the list ORDER decides which id truncates the output), a dozen ids are nothing special, and only more than LSK_MAX_EOS DISTINCT
+    # in-vocabulary ids is an error
+    assert eng._eos_array([7, 2, 7, 2, 9])[0] == [7, 2, 9]
+    assert eng._eos_array(list(range(12)))[0] == list(range(12))
+    eng.vocab = 4 * LSK_MAX_EOS
+    assert len(eng._eos_array(list(range(LSK_MAX_EOS)))[0]) == LSK_MAX_EOS
     with pytest.raises(LskError):
         eng._eos_array(list(range(LSK_MAX_EOS + 1)))
 
