@@ -89,7 +89,7 @@ CASES = {
     # 4096): a 3968-token prompt = 31 KV pages, the generation crosses into the 32nd -- the >= 3-batch page combine of the decode
     # attention, the ~4k-row prefill GEMMs / flash attention and a 32-entry block table against the unmodified reference
     "slice7b_ctx4k": StructCase("slice-7B", seed=0, prompt_len=3968, max_steps=40),
-    "slice8b_ctx4k": StructCase("slice-8B", seed=0, prompt_len=3968, max_steps=40, fp32=False),
+    "slice8b_ctx4k": StructCase("slice-8B", seed=0, prompt_len=3968, max_steps=40),      # (fp32 too: at 4k keys the reference's OWN bf16 run is ~2 ulp from it)
     # a vocabulary with one added token: V = 32 001 (not a multiple of 16: the ragged last lm_head tile; LlamaConfig of a checkpoint after
     # `resize_token_embeddings(len(tokenizer) + 1)`)
     "tiny_gqa_v32001": StructCase("tiny-gqa-v32001", seed=5, prompt_len=21, max_steps=40),
@@ -182,7 +182,11 @@ def one_dtype(ref, model_bf16, case, prompt, eos, dtype, inplace: bool, exact=No
         ref_early = ref.llama_model_utils.forward_early(model, torch.tensor([seq]), None, case.exit_layer, None).logits[0]
         my_early = lo.forward_early(om, torch.tensor([seq]), None, case.exit_layer, None).logits[0]
         assert torch.equal(ref_early, my_early), "early-exit logits are not bit-identical"
-    rows = pick_rows(len(prompt), len(seq))
+    # fp16 fixtures at FULL size record every generated position: the logits gate is a ratio of two rms errors, and the 32 entries of a row
+    # share that row's hidden-state error -- 20 rows gave the ratio a +-10 % scatter (tools/diag_fp16.py: 1.10 on the 640 recorded entries,
+    # 1.0007 over all 3.6 M entries of the 112 rows)
+    dense = LOW_DTYPE[0] == "fp16" and sum(p.numel() for p in model.parameters()) > 2e9
+    rows = pick_rows(len(prompt), len(seq), count=len(seq)) if dense else pick_rows(len(prompt), len(seq))
     rec = {
         "spec_tokens": ref_spec.predicted_tokens,
         "acceptance_rate": ref_spec.acceptance_rate,
