@@ -524,45 +524,46 @@ int lsk_embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, elem_t* dst,
 }
 
 // Prefill tile shapes (lsk_gemm_big.h): NTW 16-column tiles per wave x MT 16-row tiles per workgroup x NW waves, weight ring PB
-// K-tiles deep.  Chosen per projection and prompt length from rocprofv3 kernel times at 511 and 2047 rows:
-//   gate/up     : 128 x 128 tile, ring 2 (164 registers: three waves per SIMD; ring 4 holds two);
-//   q/k/v       : 64-row tiles (a 512-row prompt gives 768 workgroups, one full round at three per CU); eight waves (64 x 256)
-//                 once the prompt is long enough to fill the chip with those;
-//   o_proj/down : N = hidden gives 128 workgroups of 128 x 128 for 256 CUs at 512 rows: 64 x 128 tiles, ring 4, pinned
-//                 activation requests; the 128 x 128 tile once that already gives two workgroups per CU.
-template <int EPI, int NTW, int MT, int PB, int NW, bool PIN>
+// K-tiles deep, KS K-split groups per workgroup, TR = transposed product (8-byte epilogue accesses).  Chosen per projection and prompt
+// length from kernel times at 511 and 2047 rows (tools/gemm_big_bench.hip, profiles/r06_gemm_big_bench.txt):
+//   gate/up     : 128 x 128 tile, ring 2 (164 registers: three waves per SIMD; ring 4 holds two); NOT transposed (the SwiGLU epilogue
+//                 is a quarter of q/k/v's stores and the swapped operand order measures 4 % slower in the main loop);
+//   q/k/v       : transposed; 64-row tiles up to 1024 rows (a 512-row prompt gives 768 workgroups, one full round at three per CU),
+//                 128 x 128 above (2047 rows: 259 us against 287 for the 8-wave 64 x 256 form of rounds 2-5);
+//   o_proj/down : N = hidden gives 256 workgroups of 64 x 128 for 256 CUs at 512 rows -- one 4-wave workgroup per CU, one wave per
+//                 SIMD: K-split 2 (eight waves per workgroup, the two halves of K side by side: o_proj 26.9 -> 22.6 us, down 73.9 ->
+//                 67.8); the 128 x 128 tile once that already gives two workgroups per CU.
+template <int EPI, int NTW, int MT, int PB, int NW, bool PIN, int KS, bool TR>
 static int launch_big_pb(BigGemmParams& p, hipStream_t st) {
     const int rb = (p.M + MT * 16 - 1) / (MT * 16);                        // row blocks
     const int panels = (p.n_tiles + NW * NTW - 1) / (NW * NTW);            // weight panels of NW * NTW tiles
     const dim3 grid(rb * 8 * ((panels + 7) / 8));                          // XCD-aware 1-D map: lsk_gemm_big.h
-    hipLaunchKernelGGL((lsk_gemm_big_kernel<EPI, NTW, MT, PB, NW, PIN>), grid, dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((lsk_gemm_big_kernel<EPI, NTW, MT, PB, NW, PIN, KS, TR>), grid, dim3(NW * KS * 64), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
 }
 
-// PB = the deepest weight ring of {PBMAX, 2} that divides the number of K-tiles (K is a multiple of 128: run_bulk)
-template <int EPI, int NTW, int MT, int PBMAX, int NW, bool PIN>
+// PB = the deepest weight ring of {PBMAX, 2} that divides the number of K-tiles of a K-split group (K is a multiple of 128: run_bulk)
+template <int EPI, int NTW, int MT, int PBMAX, int NW, bool PIN, int KS = 1, bool TR = true>
 static int launch_big(BigGemmParams& p, hipStream_t st) {
-    const int nkt = p.K / LSK_BIG_BK;
-    if (PBMAX == 4 && nkt % 4 == 0) return launch_big_pb<EPI, NTW, MT, 4, NW, PIN>(p, st);
-    return launch_big_pb<EPI, NTW, MT, 2, NW, PIN>(p, st);
+    const int nkt = p.K / LSK_BIG_BK / KS;
+    if (PBMAX == 4 && nkt % 4 == 0) return launch_big_pb<EPI, NTW, MT, 4, NW, PIN, KS, TR>(p, st);
+    return launch_big_pb<EPI, NTW, MT, 2, NW, PIN, KS, TR>(p, st);
 }
 
-#ifndef LSK_QKV_NTW
-#define LSK_QKV_NTW 2
-#endif
-#ifndef LSK_QKV_MT
-#define LSK_QKV_MT 4
-#endif
 static int launch_big_qkv(BigGemmParams& p, hipStream_t st) {
-    return p.M > 1024 ? launch_big<EPI_QKV, 2, 4, 2, 8, false>(p, st) : launch_big<EPI_QKV, LSK_QKV_NTW, LSK_QKV_MT, 2, 4, false>(p, st);
+    return p.M > 1024 ? launch_big<EPI_QKV, 2, 8, 2, 4, false>(p, st) : launch_big<EPI_QKV, 2, 4, 2, 4, false>(p, st);
 }
 
-static int launch_big_gateup(BigGemmParams& p, hipStream_t st) { return launch_big<EPI_SWIGLU, 2, 8, 2, 4, false>(p, st); }
+static int launch_big_gateup(BigGemmParams& p, hipStream_t st) { return launch_big<EPI_SWIGLU, 2, 8, 2, 4, false, 1, false>(p, st); }
 
 static int launch_big_resid(BigGemmParams& p, hipStream_t st) {
-    const int wgs128 = ((p.M + 127) / 128) * ((p.n_tiles + 7) / 8);
-    return wgs128 >= 512 ? launch_big<EPI_RESID, 2, 8, 2, 4, false>(p, st) : launch_big<EPI_RESID, 2, 4, 4, 4, true>(p, st);
+    const int panels = (p.n_tiles + 7) / 8;
+    if (((p.M + 127) / 128) * panels >= 512) return launch_big<EPI_RESID, 2, 8, 2, 4, false>(p, st);
+    // 64-row tiles; K-split 2 while that still leaves the chip at <= 1.5 four-wave workgroups per CU (the two groups need an even
+    // number of ring-depth-2 K-tile pairs each: K a multiple of 256)
+    if (((p.M + 63) / 64) * panels <= 384 && (p.K / LSK_BIG_BK) % 4 == 0) return launch_big<EPI_RESID, 2, 4, 2, 4, true, 2>(p, st);
+    return launch_big<EPI_RESID, 2, 4, 4, 4, true>(p, st);
 }
 
 // Prompt rows [0, n) of the bulk buffer through layers [lb, le) with the MFMA-tiled prefill kernels.

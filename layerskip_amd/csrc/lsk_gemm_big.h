@@ -7,8 +7,8 @@
 // (weights) straight from the packed tiles to a PB-deep register ring per wave (each wave owns NTW adjacent 16-column
 // tiles: NTW = 2 is exactly one gate/up pair or one RoPE tile pair), one barrier per K-tile.  The block id is mapped
 // XCD-aware (see the kernel): the row blocks that share a weight panel run on ONE XCD, so the panel is fetched from
-// HBM once and re-read from that XCD's L2.  The host picks (NTW, MT, PB, NW) per projection and prompt length
-// (lsk_engine.hip, "Prefill tile shapes"); every shape walks K in the same order, so outputs are bit-identical.
+// HBM once and re-read from that XCD's L2.  The host picks (NTW, MT, PB, NW, KS, TR) per projection and prompt length
+// (lsk_engine.hip, "Prefill tile shapes"); every shape without a K-split walks K in the same order, so those outputs are bit-identical.
 // __launch_bounds__(threads, 2): without the min-waves bound hipcc budgets a 4-wave workgroup 512 registers per wave,
 // parks half of the weight ring in AGPRs and shuffles it back and forth (84 v_accvgpr moves per 128 MFMAs); with it
 // the same code takes 164-204 VGPRs, no AGPRs, two or three waves per SIMD.
@@ -56,17 +56,38 @@ struct BigGemmParams {
 // MFMAs and the LDS pipe is the first unit to saturate (one 1 KiB fragment read = 8 LDS cycles for 16 MFMA cycles, four SIMDs on one
 // LDS), so NTW sets the MFMA ceiling and MT x NTW the accumulator registers: (MT, NTW) = (8, 2) and (4, 4) both hold 64 accumulator
 // VGPRs at two waves per SIMD; (8, 4) needs 288 registers (one wave per SIMD, measured 2x slower).
-template <int EPI, int NTW, int MT, int PB, int NW, bool PIN>
-__global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmParams p) {
+//
+// KS = K-split INSIDE the workgroup (round 6).  The N = hidden projections of a 512-row prompt are 256 workgroups of 64 x 128 for 256 CUs:
+// ONE 4-wave workgroup per CU, one wave per SIMD -- nothing to switch to while a wave waits for its fragments, its barrier or its LDS
+// reads (down_proj, K = 11 008: 76 us = 600 TFLOP/s against 760 for the vendor library, profiles/r05_prefill_yardstick.json).  With KS = 2
+// the workgroup is two groups of NW waves that walk the even / the odd K-tiles with their own activation images and meet once, at the
+// end: the second group's accumulators go through LDS (fp32), the first group adds them and runs the epilogue.  Same grid, twice the
+// waves per SIMD, no traffic between workgroups.  (The summation order differs from KS = 1: only prompt rows that are not decision rows
+// pass through here, see above.)
+//
+// TR = the product is computed TRANSPOSED (round 6): the packed weight tile is the MFMA's A operand and the activation fragment its B
+// operand (the same registers, swapped: both are 16 x 32 fragments with lane l holding row l % 16, k-group l / 16), so the accumulator
+// tile is Y^T -- a lane holds FOUR CONSECUTIVE OUTPUT FEATURES of ONE row (features (l / 16) * 4 + r of row l % 16) instead of one
+// feature of four rows.  Same dot products, same k order: bit-identical sums.  What it buys is the epilogue: residual values, RoPE
+// cos / sin, the SwiGLU product and the q / K-page rows move as 8-byte accesses, a quarter of the 2-byte load / store instructions the
+// row-per-register layout needed (the q stores alone were 10 us of an 80 us q/k/v launch, profiles/r04_prefill_knockout_qkv_stores.json);
+// RoPE partners (8 columns apart in a tile) are lanes l and l ^ 32.  The V^T page ([d][slot]: consecutive SLOTS are contiguous) keeps
+// 2-byte stores: 16 lanes = 16 consecutive slots of one feature, the same 32-byte runs as before.
+template <int EPI, int NTW, int MT, int PB, int NW, bool PIN, int KS = 1, bool TR = true>
+__global__ __launch_bounds__(NW * KS * 64, 2) void lsk_gemm_big_kernel(const BigGemmParams p) {
     constexpr int BM = MT * 16;
     constexpr int SR = NW * 8;                  // rows staged per pass (8 lanes per row)
     constexpr int NP = BM / SR;                 // staging passes per K-tile
     static_assert((NW == 4 || NW == 8) && NP >= 1, "waves per workgroup");
     static_assert(MT == 2 || MT == 4 || MT == 8, "row tiles per workgroup");
     static_assert(PB >= 2 && PB % 2 == 0, "weight ring depth (K-tiles in flight per wave): even");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * LSK_BIG_LDA];
-    const int tid = threadIdx.x;
+    static_assert(KS == 1 || KS == 2, "K-split groups per workgroup");
+    static_assert(KS == 1 || NW * MT * NTW * 1024 <= KS * 2 * BM * LSK_BIG_LDA, "the accumulator hand-off reuses the activation images");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[KS * 2 * BM * LSK_BIG_LDA];
+    const int tid = (KS == 1) ? threadIdx.x : (threadIdx.x & (NW * 64 - 1));      // thread inside its K-split group
     const int lane = tid & 63;
+    const int grp = (KS == 1) ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x / (NW * 64));
+    unsigned char* lds = lds_all + grp * (2 * BM * LSK_BIG_LDA);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware block -> (row block, weight panel) map.  Workgroup b runs on XCD b % 8, each XCD has its own L2, and the RB row
     // blocks of one weight panel read the SAME weights: in a (row block, panel) grid they land on RB different XCDs and the panel
@@ -81,7 +102,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
     const int T0 = (panel * NW + w) * NTW;               // this wave's first packed tile
     if (panel * NW * NTW >= p.n_tiles) return;           // padding of the last run
     const int ksteps = p.K >> 5;
-    const int nkt = p.K / LSK_BIG_BK;
+    const int nkt = p.K / LSK_BIG_BK / KS;               // K-tiles of this group: its i-th tile is K-tile i * KS + grp
     const bool tile_ok = T0 < p.n_tiles;
 
     // A staging: a K-tile row is ONE 128-byte line (64 bf16).  Eight lanes fetch a row's line with one 16-byte load each, a wave
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
     elem8 bq[PB][NTW][2];
     auto load_a = [&](int kt, elem8 (&dst)[NP]) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) dst[i] = *(const elem8*)(aptr_i[i] + (size_t)kt * LSK_BIG_BK);
+        for (int i = 0; i < NP; ++i) dst[i] = *(const elem8*)(aptr_i[i] + (size_t)(kt * KS + grp) * LSK_BIG_BK);
     };
     auto store_a = [&](int buf, const elem8 (&src)[NP]) {
 #pragma unroll
@@ -127,7 +148,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
     auto load_b = [&](int kt, elem8 (&dst)[NTW][2]) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const size_t bo = (size_t)(kt * 2 + s) * 512;
+            const size_t bo = (size_t)((kt * KS + grp) * 2 + s) * 512;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) dst[nt][s] = *(const elem8*)(bptr[nt] + bo);
         }
@@ -158,7 +179,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
                 for (int mt = 0; mt < MT; ++mt) {
                     const elem8 a = *(const elem8*)(abase + mt * 16 * LSK_BIG_LDA + s * 64);
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = LSK_MFMA_16x16x32(a, bq[u][nt][s], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[mt][nt] = TR ? LSK_MFMA_16x16x32(bq[u][nt][s], a, acc[mt][nt], 0, 0, 0) : LSK_MFMA_16x16x32(a, bq[u][nt][s], acc[mt][nt], 0, 0, 0);
                 }
             }
             load_b(min(kt + PB, last), bq[u]);                // refill the slot just consumed
@@ -166,36 +188,135 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
             __syncthreads();
         }
     }
+    if (KS > 1) {
+        // the second group's partial sums: through LDS (the activation images are dead: the loop's last barrier is behind every wave),
+        // one 1 KiB block per (wave, row tile, column tile), lane-major -- conflict-free 16-byte accesses
+        f32x4* xch = (f32x4*)lds_all;
+        if (grp == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) xch[((w * MT + mt) * NTW + nt) * 64 + lane] = acc[mt][nt];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] += xch[((w * MT + mt) * NTW + nt) * 64 + lane];
+    }
     if (!tile_ok) return;
 
     const int c16 = lane & 15;
     const int rg = lane >> 4;
-    // Epilogue operands are requested in ONE batch, raw and from clamped (always valid) addresses, and only then consumed: with a
-    // conversion or a lane predicate at each load hipcc waited for every element where it stood (ISA of the round-2 build: 32-64
-    // "global_load_ushort; s_waitcnt vmcnt(0); global_store_short" groups in a row -- a third of a 56 us o_proj / down launch).
-    if (EPI == EPI_RESID) {
-        constexpr int MB4 = MT < 4 ? MT : 4;                  // row tiles per batch: 16 loads in flight, 16 registers
+    if (TR) {
+        // ---- transposed accumulators: acc[mt][nt][r] = Y[row m0 + 16 mt + c16][feature 16 (T0 + nt) + 4 rg + r] ----
+        typedef elem_t elem4 __attribute__((ext_vector_type(4)));
+        if (EPI == EPI_RESID) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int n = (T0 + nt) * 16 + c16;
-            const int nc = min(n, p.N - 1);
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n0 = (T0 + nt) * 16 + rg * 4;
+                const int nc = min(n0, p.N - 4);                       // (N is a multiple of 16: a tile is inside the matrix or not at all)
+                elem4 hres[MT];
 #pragma unroll
-            for (int mb = 0; mb < MT; mb += MB4) {
-                elem_t hres[MB4][4];
+                for (int mt = 0; mt < MT; ++mt) hres[mt] = *(const elem4*)(p.h + (size_t)min(m0 + mt * 16 + c16, p.M - 1) * p.ldh + nc);
 #pragma unroll
-                for (int mt = 0; mt < MB4; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int row = m0 + mt * 16 + c16;
+                    elem4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hres[mt][i] = p.h[(size_t)min(m0 + (mb + mt) * 16 + rg * 4 + i, p.M - 1) * p.ldh + nc];
+                    for (int r = 0; r < 4; ++r) o[r] = f2e(e2f(hres[mt][r]) + rnd_e(acc[mt][nt][r]));
+                    if (row < p.M && n0 < p.N) *(elem4*)(p.h + (size_t)row * p.ldh + n0) = o;
+                }
+            }
+        } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
-                for (int mt = 0; mt < MB4; ++mt)
+            for (int pr = 0; pr < NTW / 2; ++pr) {               // gate / up tiles are interleaved pairwise: the same lane holds g and u of a feature
+                const int n0 = ((T0 >> 1) + pr) * 16 + rg * 4;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int row = m0 + (mb + mt) * 16 + rg * 4 + i;
-                        if (row < p.M && n < p.N) p.h[(size_t)row * p.ldh + n] = f2e(e2f(hres[mt][i]) + rnd_e(acc[mb + mt][nt][i]));
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int row = m0 + mt * 16 + c16;
+                    elem4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = rnd_e(acc[mt][2 * pr][r]);
+                        const float uu = rnd_e(acc[mt][2 * pr + 1][r]);
+                        const float sg = rnd_e(g / (1.0f + expf(-g)));
+                        o[r] = f2e(sg * uu);
                     }
+                    if (row < p.M && n0 < (p.N >> 1)) *(elem4*)(p.act + (size_t)row * p.ldact + n0) = o;
+                }
+            }
+        } else if (EPI == EPI_QKV) {
+            const int hd = p.head_dim;
+            const int tph = hd >> 4;
+            const int nq_t = p.n_heads * tph;
+            const int nk_t = p.n_kv * tph;
+            const int base_pos = *p.kv_len + p.pos_off;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int T = T0 + nt;
+                if (T >= p.n_tiles) continue;
+                const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);
+                const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
+                const int head = TT >> lsk_tph_shift(hd);
+                const int tt = TT - head * tph;
+                // RoPE: packed column c = 4 rg + r of a q / k tile is feature tt*8 + c (c < 8) or hd/2 + tt*8 + (c - 8): four consecutive
+                // features per lane, cos / sin column j0 + r, the partner (c ^ 8) in lane l ^ 32
+                const int j0 = tt * 8 + (rg & 1) * 4;
+                const int feat0 = (kind == 2) ? tt * 16 + rg * 4 : (rg < 2 ? j0 : j0 + (hd >> 1));
+                elem4 cs4[MT], sn4[MT];
+                int pg[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int pos = base_pos + min(m0 + mt * 16 + c16, p.M - 1);
+                    pg[mt] = 0;
+                    if (kind != 2) {
+                        cs4[mt] = *(const elem4*)(p.rope_cos + (size_t)pos * (hd >> 1) + j0);
+                        sn4[mt] = *(const elem4*)(p.rope_sin + (size_t)pos * (hd >> 1) + j0);
+                    }
+                    if (kind != 0) pg[mt] = p.block_table[pos >> LSK_PAGE_SHIFT];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int row = m0 + mt * 16 + c16;
+                    const int pos = base_pos + min(row, p.M - 1);
+                    elem4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = rnd_e(acc[mt][nt][r]);
+                        if (kind != 2) {
+                            float lo = v, hi = v;
+                            lsk_row_swap32(lo, hi);                   // lo (lanes >= 32) = v of lane l - 32; hi (lanes < 32) = v of lane l + 32
+                            const float partner = rg < 2 ? hi : lo;
+                            const float a = rnd_e(v * e2f(cs4[mt][r]));
+                            const float b = rnd_e((rg < 2 ? -partner : partner) * e2f(sn4[mt][r]));
+                            v = rnd_e(a + b);
+                        }
+                        o[r] = f2e(v);
+                    }
+                    if (row < p.M) {
+                        if (kind == 0) {
+                            *(elem4*)(p.q_out + (size_t)row * p.ldq + head * hd + feat0) = o;
+                        } else {
+                            const int slot = pos & (LSK_ATTN_PAGE - 1);
+                            const size_t hb = ((size_t)pg[mt] * p.n_kv + head) * LSK_ATTN_PAGE * hd;
+                            if (kind == 1) {
+                                *(elem4*)(p.kpool + hb + (size_t)slot * hd + feat0) = o;                          // K page  [slot][d]
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) p.vpool[hb + (size_t)(feat0 + r) * LSK_ATTN_PAGE + slot] = o[r];   // V^T page [d][slot]
+                            }
+                        }
+                    }
+                }
             }
         }
-    } else if (EPI == EPI_SWIGLU) {
+        return;
+    }
+    // ---- row-per-register accumulators (TR = false: the gate/up launch): acc[mt][nt][i] = Y[row m0 + 16 mt + 4 rg + i][column c16 of tile T0 + nt] ----
+    static_assert(TR || EPI == EPI_SWIGLU, "the residual and q/k/v epilogues exist in the transposed form only");
+    if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int pr = 0; pr < NTW / 2; ++pr) {               // gate / up tiles are interleaved pairwise
             const int n = ((T0 >> 1) + pr) * 16 + c16;
@@ -211,66 +332,6 @@ __global__ __launch_bounds__(NW * 64, 2) void lsk_gemm_big_kernel(const BigGemmP
                         p.act[(size_t)row * p.ldact + n] = f2e(s * uu);
                     }
                 }
-        }
-    } else if (EPI == EPI_QKV) {
-        const int hd = p.head_dim;
-        const int tph = hd >> 4;
-        const int nq_t = p.n_heads * tph;
-        const int nk_t = p.n_kv * tph;
-        const int base_pos = *p.kv_len + p.pos_off;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int T = T0 + nt;
-            if (T >= p.n_tiles) continue;
-            const int kind = (T < nq_t) ? 0 : (T < nq_t + nk_t ? 1 : 2);
-            const int TT = (kind == 0) ? T : (kind == 1 ? T - nq_t : T - nq_t - nk_t);
-            const int head = TT >> lsk_tph_shift(hd);
-            const int tt = TT - head * tph;
-            const int j = tt * 8 + (c16 & 7);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                // this row tile's operands in one batch (cos, sin, KV page of the 4 rows of this lane), then the arithmetic
-                elem_t cs_raw[4], sn_raw[4];
-                int pg[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pos = base_pos + min(m0 + mt * 16 + rg * 4 + i, p.M - 1);
-                    cs_raw[i] = (elem_t)0.0f; sn_raw[i] = (elem_t)0.0f; pg[i] = 0;
-                    if (kind != 2) {
-                        cs_raw[i] = p.rope_cos[(size_t)pos * (hd >> 1) + j];
-                        sn_raw[i] = p.rope_sin[(size_t)pos * (hd >> 1) + j];
-                    }
-                    if (kind != 0) pg[i] = p.block_table[pos >> LSK_PAGE_SHIFT];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + mt * 16 + rg * 4 + i;
-                    const int pos = base_pos + min(row, p.M - 1);
-                    float v = rnd_e(acc[mt][nt][i]);
-                    int feat;
-                    if (kind != 2) {
-                        const float partner = row_xor8(v);
-                        const float cs = e2f(cs_raw[i]);
-                        const float sn = e2f(sn_raw[i]);
-                        const float a = rnd_e(v * cs);
-                        const float b = rnd_e((c16 < 8 ? -partner : partner) * sn);
-                        v = rnd_e(a + b);
-                        feat = (c16 < 8) ? j : j + (hd >> 1);
-                    } else {
-                        feat = tt * 16 + c16;
-                    }
-                    if (row < p.M) {
-                        if (kind == 0) {
-                            p.q_out[(size_t)row * p.ldq + head * hd + feat] = f2e(v);
-                        } else {
-                            const int slot = pos & (LSK_ATTN_PAGE - 1);
-                            const size_t hb = ((size_t)pg[i] * p.n_kv + head) * LSK_ATTN_PAGE * hd;
-                            if (kind == 1) p.kpool[hb + (size_t)slot * hd + feat] = f2e(v);        // K page  [slot][d]
-                            else p.vpool[hb + (size_t)feat * LSK_ATTN_PAGE + slot] = f2e(v);       // V^T page [d][slot]
-                        }
-                    }
-                }
-            }
         }
     }
 }

@@ -119,11 +119,14 @@ def test_fp16_struct_tokens_trace_and_logits_equal_reference(gpu_device, name):
                 within += int(abs(a - b) / u <= 1.0)
     eng.reset()
     strict = model.config.hidden_size >= 2048
-    # 1.1 x is the bf16 suite's figure (tests/test_gpu_struct_parity.py); the full-size fp16 case sits ON it (engine 0.492 vs reference
-    # 0.447 fp16 ulp rms over 640 recorded logits, both below half an ulp -- 0.289 of each is the final rounding to fp16 itself; the
-    # rms ratio of 640 samples has a standard error of ~0.03), so the full-size bound is 1.15 x, backed by the share of logits within one
-    # fp16 ulp of the reference's OWN fp16 logits (>= 97 %: the two fp16 computations agree with each other, not only with the truth)
-    tol = (1.15 if name.startswith("full") else 1.1) if strict else 1.25
+    # 1.1 x: the bf16 suite's figure (tests/test_gpu_struct_parity.py), at every BASELINE geometry.  Round 5 had widened the full-size bound
+    # to 1.15 x after measuring 0.492 vs 0.447 on the 640 entries then recorded (20 rows x 32 entries); round 6 looked for a rounding
+    # point behind it (tools/diag_fp16.py, profiles/r06_diag_fp16_full7b.json) and found none: layer by layer the engine's error on the SAME
+    # input equals the reference's fp16 run's (ratio 0.998-1.001 at all 32 layers, every stage >= 99 % bit-equal, attention closer to fp64),
+    # and over ALL 3.6 M logits of the 112 rows the two are 0.39794 vs 0.39765 fp16 ulp rms.  The 32 entries of a row share that row's
+    # hidden-state error, so 20 rows were ~20 samples of the ratio, not 640; the full-size fixture now records every generated position
+    # (52 rows, oracle/make_golden_struct.py) and the common bound holds.
+    tol = 1.1 if strict else 1.25
     msg = (f"{name}: vs the reference's fp32 logits, in fp16 ulp: engine rms {(e2 / cnt) ** 0.5:.3f} max {e_max:.2f}, reference-fp16 rms "
            f"{(r2 / cnt) ** 0.5:.3f} max {r_max:.2f}; {within}/{cnt} within 1 fp16 ulp of the reference's fp16 logits")
     print(msg)
