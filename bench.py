@@ -310,7 +310,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         avg_ms = ms / launches
         achieved = by / (ms * 1e-3) / 1e9
         traffic, source = None, None
-        for cand in ("r05_pmc_gateup.json", "r04_pmc_gateup.json", "r03_pmc_gateup.json", "r02_pmc_gateup.json", "r01_pmc_gateup.json"):
+        for cand in ("r06_pmc_gateup.json", "r05_pmc_gateup.json", "r04_pmc_gateup.json", "r03_pmc_gateup.json", "r02_pmc_gateup.json", "r01_pmc_gateup.json"):
             pmc = os.path.join(ROOT, "profiles", cand)
             if args.model == "llama2-7B" and os.path.exists(pmc):
                 # HBM bytes per launch need the PMC passes (rocprofv3 --pmc, separate runs): not collectable inside this run
@@ -320,7 +320,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         # rocprofv3's figure for the same kernel (launch-weighted AverageNs of the committed profile of this command): under the profiler
         # the kernel itself is ~2 % slower -- its preloaded kernel arguments are not delivered (profiles/r04_profile_summary.md)
         rocprof_ms, rocprof_src = None, None
-        stats_csv = next((c for c in (os.path.join(ROOT, "profiles", n) for n in ("r05_kernel_stats_7B_spec.csv", "r04_kernel_stats_7B_spec.csv"))
+        stats_csv = next((c for c in (os.path.join(ROOT, "profiles", n) for n in ("r06_kernel_stats_7B_spec.csv", "r05_kernel_stats_7B_spec.csv", "r04_kernel_stats_7B_spec.csv"))
                           if os.path.exists(c)), "")
         if args.model == "llama2-7B" and stats_csv:
             import csv
@@ -405,7 +405,7 @@ def prefill_leg(args, cfg, engine):
     engine.reset()
     tflops = flops / best / 1e12
     fetch = None
-    for cand in ("r05_pmc_hbm_traffic.csv", "r04_pmc_hbm_traffic.csv"):
+    for cand in ("r06_pmc_hbm_traffic.csv", "r05_pmc_hbm_traffic.csv", "r04_pmc_hbm_traffic.csv"):
         pmc = os.path.join(ROOT, "profiles", cand)
         if args.model == "llama2-7B" and os.path.exists(pmc):
             # HBM reads of the prefill projections over their packed weights (PMC FETCH_SIZE pass of a 512-token prompt, x2 gfx950
@@ -417,8 +417,14 @@ def prefill_leg(args, cfg, engine):
                     epi = int(r["kernel"].split("lsk_gemm_big_kernel<")[1].split(",")[0])
                     got[epi] = float(r["hbm_read_bytes_x2"])
             weights = {1: (2 * H * nh * hd + 2 * H * I) / 2.0, 2: 2 * 2 * H * I, 3: 2 * H * (nh + 2 * nkv) * hd}     # EPI_RESID: o_proj / down average
+            # the activation panel [rows][K] is fetched once by EVERY XCD's L2 (the XCD-aware block map gives each XCD whole weight panels and
+            # therefore all the row blocks): 8 x rows x K x 2 B per launch are part of FETCH_SIZE and are not weight re-reads
+            acts = {1: 8 * rows * (nh * hd + I) * 2 / 2.0, 2: 8 * rows * H * 2, 3: 8 * rows * H * 2}
             if set(got) == {1, 2, 3}:
-                fetch = {"value": round((2 * got[1] + got[2] + got[3]) / (2 * weights[1] + weights[2] + weights[3]), 3),
+                total, w_all, a_all = 2 * got[1] + got[2] + got[3], 2 * weights[1] + weights[2] + weights[3], 2 * acts[1] + acts[2] + acts[3]
+                fetch = {"value": round(total / w_all, 3), "weights_only": round((total - a_all) / w_all, 3),
+                         "note": "value = FETCH_SIZE over the packed weights; weights_only = the same after subtracting the activation panel's one fetch per XCD "
+                                 "(8 x rows x K x 2 B per launch, inherent to the XCD-aware block map)",
                          "source": f"REPLAYED from profiles/{cand} (rocprofv3 --pmc FETCH_SIZE, per launch, x2 gfx950 correction); not measured by this run"}
             break
     return {"rows": rows, "ms": round(1e3 * best, 3), "tflops": round(tflops, 1), "peak_tflops": MFMA_PEAK_TFLOPS,

@@ -435,6 +435,10 @@ static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
     return 0;
 }
 
+// (measurement builds: -DLSK_OPROJ_WGS=128 gives the o_proj launch 128 workgroups of two tiles instead of 256 of one)
+#ifndef LSK_OPROJ_WGS
+#define LSK_OPROJ_WGS 0
+#endif
 // decoder layers [lb, le) in place over rows of `x` (positions *base_ptr + pos_off + i)
 int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st) {
     const lsk_config& c = e->cfg;
@@ -465,7 +469,7 @@ int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int
             p.h = x; p.ldh = c.hidden;
             hipEvent_t ea = nullptr, eb = nullptr;
             LSK_TRY(profile_pair(e, LSK_PROF_OPROJ, m, (double)p.wp_bytes, &ea, &eb));
-            LSK_TRY((launch_gemm<PRO_PLAIN, EPI_RESID>(p, e->target_wgs, st, nullptr, ea, eb)));
+            LSK_TRY((launch_gemm<PRO_PLAIN, EPI_RESID>(p, LSK_OPROJ_WGS > 0 ? LSK_OPROJ_WGS : e->target_wgs, st, nullptr, ea, eb)));
         }
         {   // post-attention RMSNorm -> gate/up -> SiLU * up
             GemmParams p{};

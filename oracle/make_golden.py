@@ -97,7 +97,7 @@ def topk_rows(logits: torch.Tensor, rows, k=8):
 
 
 def one_dtype(ref, model_bf16, case, prompt, eos, dtype):
-    model = copy.deepcopy(model_bf16).to(dtype)
+    model = ref_shim.cast_parameters(copy.deepcopy(model_bf16), dtype)       # as from_pretrained(torch_dtype=dtype) does: buffers (inv_freq) untouched
     ref_shim.patch_model(model)
     ref_spec = run_reference(ref, model, prompt, eos, case, "self_speculative")
     ref_ar = run_reference(ref, model, prompt, eos, case, "autoregressive")

@@ -156,12 +156,9 @@ def one_dtype(ref, model_bf16, case, prompt, eos, dtype, inplace: bool, exact=No
     """exact: (seq, full-depth fp32 logits, early-exit fp32 logits) of the reference's fp32 run, or None.
     inplace (multi-GB checkpoints): the ONE model object is converted to `dtype` in place -- bf16 -> fp32 -> bf16 is exact,
     the values are bf16-representable -- so the fp32 run of a 7-8B model needs 32 GB, not 16 + 32."""
-    if inplace:
-        model = model_bf16
-        for prm in model.parameters():
-            prm.data = prm.data.to(dtype)
-    else:
-        model = copy.deepcopy(model_bf16).to(dtype)
+    # parameters only, like the reference's `from_pretrained(..., torch_dtype=dtype)` (generate.py:59-64): the rotary inv_freq buffer stays
+    # fp32 (ref_shim.cast_parameters; `model.to(dtype)` would round it)
+    model = ref_shim.cast_parameters(model_bf16 if inplace else copy.deepcopy(model_bf16), dtype)
     ref_shim.patch_model(model)
     t0 = time.time()
     ref_spec = run_reference(ref, model, prompt, eos, case, "self_speculative")
@@ -182,10 +179,10 @@ def one_dtype(ref, model_bf16, case, prompt, eos, dtype, inplace: bool, exact=No
         ref_early = ref.llama_model_utils.forward_early(model, torch.tensor([seq]), None, case.exit_layer, None).logits[0]
         my_early = lo.forward_early(om, torch.tensor([seq]), None, case.exit_layer, None).logits[0]
         assert torch.equal(ref_early, my_early), "early-exit logits are not bit-identical"
-    # fp16 fixtures at FULL size record every generated position: the logits gate is a ratio of two rms errors, and the 32 entries of a row
+    # fp16 fixtures at BASELINE geometry (hidden >= 2048: the strict gate) record every generated position: the logits gate is a ratio of two rms errors, and the 32 entries of a row
     # share that row's hidden-state error -- 20 rows gave the ratio a +-10 % scatter (tools/diag_fp16.py: 1.10 on the 640 recorded entries,
     # 1.0007 over all 3.6 M entries of the 112 rows)
-    dense = LOW_DTYPE[0] == "fp16" and sum(p.numel() for p in model.parameters()) > 2e9
+    dense = LOW_DTYPE[0] == "fp16" and model.config.hidden_size >= 2048
     rows = pick_rows(len(prompt), len(seq), count=len(seq)) if dense else pick_rows(len(prompt), len(seq))
     rec = {
         "spec_tokens": ref_spec.predicted_tokens,

@@ -134,3 +134,15 @@ def load_reference():
     ns.self_speculation_generator = importlib.import_module("self_speculation.self_speculation_generator")
     _LOADED = ns
     return ns
+
+
+def cast_parameters(model, dtype):
+    """What the reference's loader leaves behind (generate.py:59-64: `from_pretrained(..., torch_dtype=dtype)`): every PARAMETER in
+    `dtype`, the buffers -- the rotary `inv_freq` -- as the modules' `__init__` made them (fp32; checked against
+    `AutoModelForCausalLM.from_pretrained(dir, dtype=...)` of transformers 5.15).  `model.to(dtype)` is NOT that: `nn.Module.to` casts
+    floating-point buffers too, and an `inv_freq` rounded to bf16 is off by 2e-3 relative -- 8 rad of rotary angle at position 4 000.
+    (Rounds 2-5 generated the fixtures of every checkpoint below 2e9 parameters that way; round 6 regenerated them.)  In place."""
+    for prm in model.parameters():
+        prm.data = prm.data.to(dtype)
+    return model
+

@@ -98,6 +98,15 @@ def build_struct_model(rec, device="cpu"):
     return copy.deepcopy(cached) if key in _STRUCT_CPU_CACHE else cached
 
 
+def cast_parameters(model, dtype):
+    """The model as `from_pretrained(..., torch_dtype=dtype)` hands it to the reference (generate.py:59-64): parameters in `dtype`, buffers
+    (the rotary inv_freq) untouched.  `model.to(dtype)` would round inv_freq too (oracle/ref_shim.py::cast_parameters: the fixtures are
+    generated this way)."""
+    for prm in model.parameters():
+        prm.data = prm.data.to(dtype)
+    return model
+
+
 def bf16_ulp(value):
     """Spacing of bf16 numbers at |value| (python float)."""
     import math

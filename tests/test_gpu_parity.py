@@ -46,7 +46,15 @@ def _first_mismatch(a, b):
     return None if len(a) == len(b) else min(len(a), len(b))
 
 
-@pytest.mark.parametrize("name", golden_names())
+# The two random-init fixtures at BASELINE / wide geometry are superseded on the GPU by fixtures that assert MORE on the same geometry -- the
+# structured family (tests/golden/struct/slice7b, small_wide: ids, traces, draft tokens, logits with no tie branch) and the full-size
+# random-init family (tests/test_gpu_rand7b_parity.py) -- and cost ~27 s of the driver's GPU suite; the CPU suite still pins them to the
+# oracle (tests/test_oracle_golden.py).
+SUPERSEDED = ("slice7b_s0", "small_wide_s0")
+NAMES = [n for n in golden_names() if n not in SUPERSEDED]
+
+
+@pytest.mark.parametrize("name", NAMES)
 def test_spec_tokens_match_reference(gpu_device, name):
     rec = load_golden(name)
     model = _model(rec, gpu_device)
@@ -65,7 +73,7 @@ def test_spec_tokens_match_reference(gpu_device, name):
                                   f"at a healthy reference margin {margins[i]:.4f}")
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", NAMES)
 def test_spec_equals_autoregressive_in_engine(gpu_device, name):
     """The reference's own correctness criterion (correctness.py:82-88), bit-exact here by construction."""
     rec = load_golden(name)
@@ -79,7 +87,7 @@ def test_spec_equals_autoregressive_in_engine(gpu_device, name):
     assert len(a.predicted_tokens) <= rec["max_steps"]
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if not n.endswith("_eos")])
+@pytest.mark.parametrize("name", [n for n in NAMES if not n.endswith("_eos")])
 def test_teacher_forced_logits(gpu_device, name):
     """Engine logits along the REFERENCE trajectory vs the recorded reference logits rows."""
     from layerskip_amd.engine import BUF_BULK, BUF_STEP, get_engine

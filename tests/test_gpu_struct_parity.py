@@ -267,6 +267,12 @@ def test_logits_on_the_live_kv_state_after_rollbacks(gpu_device, name, mode):
     assert int(buf[0].argmax()) == max(zip(row["val"], row["idx"]))[1], msg
     if strict and stats.reference_is_far():          # the `_ctx4k` fixtures: the fp32 gate (see _LogitStats.check)
         assert stats.eng2 <= 1.1 ** 2 * stats.ref2 and stats.eng_max <= stats.ref_max + 0.5, msg
+    elif strict:
+        assert stats.worst <= 2.0 and stats.within >= 0.9 * stats.n, msg
     else:
-        assert stats.worst <= (2.0 if strict else 8.0) and stats.within >= (0.9 if strict else 0.7) * stats.n, msg
+        # tiny shapes (H = 256 / 512): the reference's own bf16 row is 0.6-1.3 ulp rms from its fp32 row, so "within one ulp of the
+        # reference's bf16 value" is only asked of 70 % of the entries -- unless the engine is CLOSER to the fp32 row than the reference's
+        # bf16 run is (then the entries on which the two bf16 computations part are the reference's roundings, not the engine's)
+        closer = stats.n32 and stats.eng2 <= stats.ref2 and stats.eng_max <= stats.ref_max
+        assert stats.worst <= 8.0 and (stats.within >= 0.7 * stats.n or closer), msg
     print(msg)

@@ -15,7 +15,7 @@ import os
 import pytest
 import torch
 
-from conftest import build_case_model
+from conftest import build_case_model, cast_parameters
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +29,7 @@ def test_fp16_engine_matches_reference_and_itself(gpu_device, name):
     from layerskip_amd import GenerationConfig
     from layerskip_amd.hip_strategies import HipAutoRegressiveGenerationStrategy, HipSelfSpeculativeGenerationStrategy
     rec = json.load(open(os.path.join(FP16_DIR, name + ".json")))
-    model = build_case_model(rec).to(torch.float16).to(gpu_device)
+    model = cast_parameters(build_case_model(rec), torch.float16).to(gpu_device)
     kw = dict(max_steps=rec["max_steps"], num_speculations=rec["num_speculations"], sample=False)
     spec = HipSelfSpeculativeGenerationStrategy().generate_token_ids(
         model, rec["prompt"], rec["eos_token_ids"],
@@ -69,7 +69,7 @@ def test_fp16_struct_tokens_trace_and_logits_equal_reference(gpu_device, name):
     rec = json.load(open(os.path.join(STRUCT16_DIR, name + ".json")))
     gold = rec["fp16"]
     assert gold["min_margin_ulp"] >= 16 and gold["min_draft_margin_ulp"] >= 16        # (bf16 ulps: >= 128 fp16 ulps -- no tie branch below)
-    model = build_struct_model(rec, "cpu").to(torch.float16).to(gpu_device)        # what `torch_dtype=torch.float16` does to a bf16 checkpoint
+    model = cast_parameters(build_struct_model(rec, "cpu"), torch.float16).to(gpu_device)      # what `torch_dtype=torch.float16` does to a bf16 checkpoint
     kw = dict(max_steps=rec["max_steps"], num_speculations=rec["num_speculations"], sample=False)
     cfg_spec = GenerationConfig(generation_strategy="self_speculative", exit_layer=rec["exit_layer"], **kw)
     fused = HipSelfSpeculativeGenerationStrategy()

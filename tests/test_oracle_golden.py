@@ -89,7 +89,7 @@ def test_restatement_is_bit_identical_to_unmodified_reference():
     rec = load_golden("tiny_mha_s1")
     base = build_case_model(rec)
     for dtype in (torch.float32, torch.bfloat16):
-        model = ref_shim.patch_model(copy.deepcopy(base).to(dtype))
+        model = ref_shim.patch_model(ref_shim.cast_parameters(copy.deepcopy(base), dtype))
         cfg = ref.generator_base.GenerationConfig(max_steps=20, exit_layer=rec["exit_layer"],
                                                   num_speculations=rec["num_speculations"], sample=False)
         with torch.inference_mode():

@@ -15,6 +15,7 @@ reference's own fp16 run 0.447 -- in bf16 the engine is the closer one.  A consi
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 
@@ -237,14 +238,15 @@ def main():
     dev = torch.device("cuda:0")
     report = {"subnormal_probe": subnormal_probe(dev)}
     rec = json.load(open(os.path.join(ROOT, "tests", "golden", "struct_fp16", args.name + ".json")))
-    # what `torch_dtype=torch.float16` does to the bf16 checkpoint (oracle/make_golden_struct.py --dtype fp16 and tests/test_gpu_zz_fp16.py do
-    # exactly this): `.to(float16)` converts the BUFFERS too -- the rotary inv_freq -- so the reference, the truth and the engine below all
-    # see the same (rounded) frequencies
-    model_cpu = build_struct_model(rec, "cpu").to(torch.float16)
+    # what `torch_dtype=torch.float16` does to the bf16 checkpoint (generate.py:59-64): the PARAMETERS become fp16, the rotary inv_freq
+    # buffer stays fp32 -- `model.to(float16)` would round it (the first version of this tool did, like rounds 2-5's fixture recipe for
+    # checkpoints below 2e9 parameters: the "rounding point" behind the fp16 gate's 1.10 was there, not in a kernel)
+    from conftest import cast_parameters
+    model_cpu = cast_parameters(build_struct_model(rec, "cpu"), torch.float16)
     om16 = lo.OracleModel.from_hf(model_cpu)
     om32 = lo.OracleModel.from_hf(model_cpu, dtype=torch.float32)
     print("  inv_freq dtype of the converted model:", model_cpu.model.rotary_emb.inv_freq.dtype, flush=True)
-    model = build_struct_model(rec, "cpu").to(torch.float16).to(dev)
+    model = cast_parameters(build_struct_model(rec, "cpu"), torch.float16).to(dev)
     eng = get_engine(model)
     seq = rec["prompt"] + rec["fp16"]["spec_tokens"]
     n = len(seq)
@@ -314,6 +316,40 @@ def main():
                "engine_vs_reference_bit_equal_share": float((e_log == r_log).float().mean())}
         print("  end to end, logits in fp16 ulp of the fp32 logits:", json.dumps(end), flush=True)
         report["end_to_end"] = end
+        # ---- the test's own statistic (tests/test_gpu_zz_fp16.py) on the fixture's recorded entries, split by what it mixes: full-depth /
+        #      early-exit rows, top-16 / strided entries; against the fixture's fp32 values AND against this tool's fp32 oracle ----
+        gate = {}
+        for key, layer_end in (("logits", eng.num_layers), ("early_logits", rec["exit_layer"])):
+            eng.reset()
+            eng.embed_rows(seq, BUF_BULK, 0)
+            eng.run_layers_chunked(BUF_BULK, 0, n, 0, 0, layer_end)
+            with torch.inference_mode():
+                if key == "logits":
+                    o32, o16 = t_log, r_log
+                else:
+                    o32 = lo.forward_early(om32, torch.tensor([seq]), None, rec["exit_layer"], None).logits[0].double()
+                    o16 = lo.forward_early(om16, torch.tensor([seq]), None, rec["exit_layer"], None).logits[0].double()
+            acc = {}
+            for row in rec["fp16"][key]:
+                buf = torch.empty(1, eng.vocab, dtype=torch.float32, device=dev)
+                eng.run_head(BUF_BULK, row["row"], 1, logits=buf, want_tokens=False)
+                mine = buf[0].cpu().double()
+                order = sorted(range(len(row["idx"])), key=lambda i: -row["val"][i])
+                top = set(order[:16])
+                for i, (idx, b, x) in enumerate(zip(row["idx"], row["val"], row["val_fp32"])):
+                    cls = "top16" if i in top else "strided"
+                    a = float(mine[idx])
+                    u = 2.0 ** (math.floor(math.log2(max(abs(x), 1.0))) - 10)
+                    u2 = 2.0 ** (math.floor(math.log2(max(abs(float(o32[row["row"], idx])), 1.0))) - 10)
+                    d = acc.setdefault(cls, [0.0] * 8)
+                    d[0] += ((a - x) / u) ** 2; d[1] += ((b - x) / u) ** 2; d[2] += 1
+                    d[3] += ((a - float(o32[row["row"], idx])) / u2) ** 2; d[4] += ((float(o16[row["row"], idx]) - float(o32[row["row"], idx])) / u2) ** 2
+                    d[5] += float(float(o16[row["row"], idx]) == b); d[6] += ((x - float(o32[row["row"], idx])) / u) ** 2
+            gate[key] = {c: {"n": int(d[2]), "engine_vs_fixture_fp32": (d[0] / d[2]) ** 0.5, "reference_vs_fixture_fp32": (d[1] / d[2]) ** 0.5,
+                             "engine_vs_tool_fp32": (d[3] / d[2]) ** 0.5, "tool_fp16_vs_tool_fp32": (d[4] / d[2]) ** 0.5,
+                             "tool_fp16_equals_fixture_fp16_share": d[5] / d[2], "fixture_fp32_vs_tool_fp32": (d[6] / d[2]) ** 0.5} for c, d in acc.items()}
+            print(f"  fixture gate, {key}:", json.dumps(gate[key]), flush=True)
+        report["fixture_gate"] = gate
     for l in [int(v) for v in args.stages.split(",") if v != ""]:
         if l in layer_inputs:
             report[f"stages_layer_{l}"] = stage_pass(eng, om16, l, layer_inputs[l], n, dev)
