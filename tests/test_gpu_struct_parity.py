@@ -102,11 +102,6 @@ class _LogitStats:
                 self.eng_max, self.ref_max = max(self.eng_max, ee), max(self.ref_max, er)
                 self.n32 += 1
 
-    def reference_is_far(self):
-        """The reference's own bf16 logits are more than 0.6 bf16 ulp (rms) from its fp32 logits of the same entries (at the short contexts
-        of the other BASELINE-geometry fixtures: 0.44-0.50; at ~4 000 keys: 0.7-2.0)."""
-        return bool(self.n32) and (self.ref2 / self.n32) ** 0.5 > 0.6
-
     def describe(self):
         s = (f"{self.within}/{self.n} within 1 bf16 ulp of the reference's bf16 logits, worst {self.worst:.2f} ulp, "
              f"max abs err {self.max_abs:.4f}")
@@ -131,12 +126,6 @@ class _LogitStats:
             # or, where the 1-ulp share falls short of 99 % (full-size llama3-8B: 98.9 %), the engine must be at least as
             # close to the reference's FP32 logits as the reference's own bf16 run is (both are bf16 computations of the
             # same function; neither is the other's ground truth)
-            if self.reference_is_far():
-                # at the context limit (the `_ctx4k` fixtures: ~4 000 keys) the reference's OWN bf16 run sits ~2 ulp rms from its fp32 run
-                # (its attention at that length, not a decision-relevant error on these checkpoints): neither bf16 computation is the
-                # other's ground truth, so the gate is the fp32 one -- the engine at least as close to it as the reference's bf16 run
-                assert self.eng2 <= 1.1 ** 2 * self.ref2 and self.eng_max <= self.ref_max + 0.5, msg
-                return msg
             assert self.worst <= 2.0, msg
             if self.within < 0.99 * self.n:
                 assert self.n32 and self.within >= 0.98 * self.n, msg
@@ -228,7 +217,8 @@ def test_logits_on_the_live_kv_state_after_rollbacks(gpu_device, name, mode):
     Modes: the fused one-call generation (steps pipelined on the stream), one call per step, hipGraph-replayed steps, and the
     layer pipeline's protocol (one rank: draft blocks + optimistic bookkeeping through the building-block API).
     The `_ctx4k` fixtures put this at the context limit the reference reaches (LMU:45-59; llama2: 4096): a 3968-token prompt = 31 KV pages
-    through the ~4k-row prefill GEMMs / flash attention, the live row attends over 32 pages (four batches of the last arriver's page combine)."""
+    through the ~4k-row prefill GEMMs / flash attention, the live row attends over 32 pages (four batches of the last arriver's page combine);
+    the gate is the one of the short contexts (<= 2 bf16 ulp from the reference's bf16 logits everywhere, <= 1 on 90 %)."""
     from layerskip_amd import _lib
     from layerskip_amd.engine import BUF_STEP, get_engine
     from layerskip_amd.hip_strategies import HipSelfSpeculativeGenerationStrategy
@@ -265,14 +255,5 @@ def test_logits_on_the_live_kv_state_after_rollbacks(gpu_device, name, mode):
     strict = model.config.hidden_size >= 2048
     msg = f"{name} / {mode}: " + stats.describe() + f"; max abs err {max(abs(a - b) for a, b in zip(mine, row['val'])):.4f}"
     assert int(buf[0].argmax()) == max(zip(row["val"], row["idx"]))[1], msg
-    if strict and stats.reference_is_far():          # the `_ctx4k` fixtures: the fp32 gate (see _LogitStats.check)
-        assert stats.eng2 <= 1.1 ** 2 * stats.ref2 and stats.eng_max <= stats.ref_max + 0.5, msg
-    elif strict:
-        assert stats.worst <= 2.0 and stats.within >= 0.9 * stats.n, msg
-    else:
-        # tiny shapes (H = 256 / 512): the reference's own bf16 row is 0.6-1.3 ulp rms from its fp32 row, so "within one ulp of the
-        # reference's bf16 value" is only asked of 70 % of the entries -- unless the engine is CLOSER to the fp32 row than the reference's
-        # bf16 run is (then the entries on which the two bf16 computations part are the reference's roundings, not the engine's)
-        closer = stats.n32 and stats.eng2 <= stats.ref2 and stats.eng_max <= stats.ref_max
-        assert stats.worst <= 8.0 and (stats.within >= 0.7 * stats.n or closer), msg
+    assert stats.worst <= (2.0 if strict else 8.0) and stats.within >= (0.9 if strict else 0.7) * stats.n, msg
     print(msg)

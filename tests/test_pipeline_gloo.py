@@ -74,7 +74,10 @@ def _worker(rank, world, port, queue):
             eos = res.predicted_tokens[5]
         t = torch.tensor([eos if eos is not None else 0])
         dist.broadcast(t, src=0)
-        res2 = dec.generate(prompt if rank == 0 else None, [int(t.item())], 18, S)
+        # ... listed LAST of twelve ids, the other eleven never produced (the reference folds any number of stop_token_ids into the list,
+        # generator_base.py:106): the ids travel to the late ranks in a broadcast of their own, sized by the count in the set-up words
+        eos_list = [cfg.vocab_size - 1 - i for i in range(11)] + [int(t.item())]
+        res2 = dec.generate(prompt if rank == 0 else None, eos_list if rank == 0 else [], 18, S)
         if rank == 0:
             queue.put((res.predicted_tokens, res.acceptance_rate, res.steps, res2.predicted_tokens, int(t.item())))
     finally:
@@ -111,9 +114,11 @@ def test_pipeline_matches_single_process(world):
     assert [list(s) for s in steps] == [[s.num_drafts, s.num_matches] for s in want.steps]
     from oracle import llama_oracle as lo
     with torch.inference_mode():
-        want_eos = lo.self_speculative_generate(om, prompt, [eos], 18, 2, 4)
+        eos_list = [om.embed.shape[0] - 1 - i for i in range(11)] + [eos]
+        assert not any(t in want.predicted_tokens for t in eos_list[:11])
+        want_eos = lo.self_speculative_generate(om, prompt, eos_list, 18, 2, 4)
     assert tokens_eos == want_eos.predicted_tokens
-    assert eos not in tokens_eos
+    assert eos not in tokens_eos and len(tokens_eos) < len(tokens)
 
 
 @pytest.mark.parametrize("world,override_frac,optimistic", [(2, 0.0, True), (3, 0.3, True), (2, 0.3, False)])
