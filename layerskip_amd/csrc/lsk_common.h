@@ -21,11 +21,11 @@ typedef __bf16 elem8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define LSK_WAVES 8            // waves per projection workgroup (split-K factor inside a WG)
-#define LSK_THREADS 512
-#define LSK_KC_STEPS 128       // 32-wide k-steps per K-chunk of a workgroup (= 4096 features)
-#define LSK_KC_ELEMS 4096
+#define LSK_WAVES 8            // waves per projection workgroup at most (the split-K factor inside a workgroup is 8 or 4: lsk_gemm_waves, lsk_gemm.h)
 #define LSK_SPW 16             // k-steps per wave per (tile, chunk) unit = depth of the weight ring
+#ifndef LSK_FORCE_WAVES
+#define LSK_FORCE_WAVES 0      // measurement builds: -DLSK_FORCE_WAVES=8 (rounds 1-5's shape everywhere) or 4
+#endif
 #define LSK_ROWS 16
 #define LSK_HDR_WORDS 40           // int32 words of the layer pipeline's message header (layout: lsk_accept.h); must fit ONE hidden row
 #define LSK_ATTN_PAGE 128          // KV page size == keys per decode-attention workgroup

@@ -5,8 +5,8 @@
 //   * weights are pre-packed into 16(n) x 32(k) MFMA B-fragment tiles (lsk_pack_linear): every
 //     wave-wide load is ONE contiguous 1 KiB non-temporal buffer_load_dwordx4, straight to VGPRs
 //     (no LDS round trip: each byte is used by exactly one wave, once);
-//   * a workgroup = 8 waves that split K between them (wave w owns a contiguous run of <= 16
-//     k-steps of every 4096-wide K-chunk).  Each wave keeps a 16-deep ring of weight fragments in
+//   * a workgroup = 8 or 4 waves that split K between them (wave w owns a contiguous run of <= 16
+//     k-steps of every 4096- / 2048-wide K-chunk; which of the two: lsk_gemm_waves below, by kernel and K).  Each wave keeps a 16-deep ring of weight fragments in
 //     flight (16 KiB / wave, 128 KiB / workgroup) and refills a slot the moment the MFMA consumed it,
 //     across tile and chunk boundaries, so the HBM pipe never drains inside a launch;
 //   * the activation rows (1..16, RMSNorm fused) are staged once per K-chunk in LDS as bf16 rows and
@@ -49,21 +49,40 @@ struct UnitInfo {
     int steps_c;     // k-steps of the chunk
 };
 
+template <int NW>
 __device__ __forceinline__ UnitInfo lsk_unit_info(int u, int units, int ntl, int ksteps, int tile0, int w, int lane) {
+    constexpr int WAVES = NW, KC_STEPS = NW * LSK_SPW;
     UnitInfo r;
     if (u >= units) { r.off0 = 0; r.nvalid = 0; r.c = 0; r.tl = 0; r.ks0 = 0; r.steps_c = 1; return r; }
     const int c = u / ntl;
     const int tl = u - c * ntl;
-    const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
-    const int spw = (steps_c + LSK_WAVES - 1) / LSK_WAVES;
+    const int steps_c = min(KC_STEPS, ksteps - c * KC_STEPS);
+    const int spw = (steps_c + WAVES - 1) / WAVES;
     const int ks0 = w * spw;
     r.c = c; r.tl = tl; r.ks0 = ks0; r.steps_c = steps_c;
     r.nvalid = max(0, min(spw, steps_c - ks0));
-    r.off0 = ((unsigned)(tile0 + tl) * (unsigned)ksteps + (unsigned)(c * LSK_KC_STEPS + ks0)) * 1024u + (unsigned)lane * 16u;
+    r.off0 = ((unsigned)(tile0 + tl) * (unsigned)ksteps + (unsigned)(c * KC_STEPS + ks0)) * 1024u + (unsigned)lane * 16u;
     return r;
 }
 
 #define LSK_OOB_OFFSET 0xF0000000u
+
+// ---- workgroup geometry: NW waves split the k-steps of a K-chunk of NW x 16 x 32 features, 16 k-steps (= the ring depth) per wave ----
+// 8 waves / 4096-feature chunks are the shape of rounds 1-5.  Round 6 (profiles/r06_ab_1B_options.json,
+// r06_ab_waves_per_projection.json): with 4 waves / 2048-feature chunks llama3.2-1B decodes 7 % faster (q/k/v 5.68 -> 4.53 us, gate/up 12.6 -> 11.3,
+// down 7.7 -> 7.2) -- at K = 2048 eight waves own 8 k-steps each, HALF a ring, and pay an 8-wave reduction + barrier per tile for it;
+// the launches without an RMSNorm prologue are faster at every size (o_proj 7B 6.80 -> 6.39 us, 13B 11.6 -> 9.8; down 13B 26.1 -> 22.6),
+// the lm_head a little (13B 54.4 -> 50.9), and so are the RMSNorm launches of models wider than one 4096-chunk, whose last chunk gave
+// eight waves a fraction of a ring (llama2-13B, K = 5120: q/k/v 27.2 -> 26.2 / 31.1 -> 29.2 us, gate/up 46.9 -> 44.3 / 50.4 -> 46.9;
+// llama2-70B gate/up 139 -> 135).  Only the RMSNorm launches of a 4096-wide model keep eight waves: their multi-row form has the
+// one-chunk split prologue (q/k/v 18.8 -> 19.5 us with four waves and two chunks), their one-row form is the same either way.
+// A function of (kernel, K) only -- never of the row count -- so the summation order of an output element still depends on nothing
+// but its projection: row invariance holds.
+__host__ __device__ inline int lsk_kc_elems(int nw) { return nw * LSK_SPW * 32; }
+__host__ inline int lsk_gemm_waves(int pro, int epi, int K) {
+    if (LSK_FORCE_WAVES) return LSK_FORCE_WAVES;
+    return (pro == PRO_PLAIN || epi == EPI_HEAD || K <= 2048 || K > 4096) ? 4 : 8;
+}
 
 // LDS carve (bytes)
 #define LSK_LDS_SLAB 0          // [2][8][256] f32 = 16384
@@ -75,21 +94,22 @@ __device__ __forceinline__ UnitInfo lsk_unit_info(int u, int units, int ntl, int
 
 // +32 B per row: the 16-B slot of (row r, k-group g) in a 256-B bank row is (2r + g) mod 16, a bijection inside every
 // 16-lane service group of ds_read_b128 (with +16 B it was r + g: 2-way conflicts, SQ_LDS_BANK_CONFLICT 34 % at M = 7)
-__host__ __device__ inline int lsk_gemm_xstride(int K) { return (K < LSK_KC_ELEMS ? K : LSK_KC_ELEMS) * 2 + 32; }
-__host__ inline size_t lsk_gemm_lds_bytes(int M, int K) { return (size_t)LSK_LDS_X + (size_t)M * lsk_gemm_xstride(K); }
+__host__ __device__ inline int lsk_gemm_xstride(int K, int nw) { return (K < lsk_kc_elems(nw) ? K : lsk_kc_elems(nw)) * 2 + 32; }
+__host__ inline size_t lsk_gemm_lds_bytes(int M, int K, int nw) { return (size_t)LSK_LDS_X + (size_t)M * lsk_gemm_xstride(K, nw); }
 
 // Activation staging is split in two so that no global load of x ever sits BEHIND the weight ring in a
 // wave's (in-order) load queue: `lsk_load_chunk` pulls this thread's 16-byte slice of every row of a
 // K-chunk into registers (issued before / under the weight stream), `lsk_store_chunk` applies the
 // RMSNorm (if any) and writes the bf16 rows to LDS later, without touching global memory.
-template <int PRO, int MB>
+template <int PRO, int MB, int NW>
 __device__ __forceinline__ void lsk_load_chunk(const GemmHot& p, int c, int steps_c, int tid, elem8 (&xr)[MB], elem8& nw) {
+    constexpr int KC_ELEMS = NW * LSK_SPW * 32;
     if (PRO == PRO_PLAIN) {
         // EVERY thread loads, from a clamped (always valid) slice: no exec-masked region around the loads.  Inside such a region
         // hipcc ended the branch with register copies of the last row's value -- an s_waitcnt on 8 of the 12 outstanding loads in
         // front of the weight ring of every multi-row o_proj / down launch.  A thread beyond a short chunk re-reads the chunk's
         // last slice; what it loaded is never stored (lsk_store_chunk).
-        const int k0 = c * LSK_KC_ELEMS + min(tid * 8, steps_c * 32 - 8);
+        const int k0 = c * KC_ELEMS + min(tid * 8, steps_c * 32 - 8);
 #pragma unroll
         for (int i = 0; i < MB; ++i) xr[i] = *(const elem8*)(p.x + (size_t)min(i, p.M - 1) * p.ldx + k0);
         return;
@@ -97,7 +117,7 @@ __device__ __forceinline__ void lsk_load_chunk(const GemmHot& p, int c, int step
     // (the RMSNorm form keeps the guarded loads: its 16-row template sits at the register limit and the branch-free form spills)
     const int e0 = tid * 8;
     if (e0 < steps_c * 32) {
-        const int k0 = c * LSK_KC_ELEMS + e0;
+        const int k0 = c * KC_ELEMS + e0;
         nw = *(const elem8*)(p.norm_w + k0);
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
@@ -162,8 +182,9 @@ __device__ __forceinline__ void lsk_head_tile(const GemmParams& p, const f32x4& 
     }
 }
 
-template <int PRO, int EPI, int MB>
+template <int PRO, int EPI, int MB, int NW>
 __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParams& p, const int block_id, unsigned char* smem) {
+    constexpr int WAVES = NW, THREADS = NW * 64, KC_STEPS = NW * LSK_SPW;        // the workgroup's geometry (lsk_gemm_waves): 8 or 4 waves
     // q/k/v: the verified context length is read FIRST (its pointer is a preloaded argument): the answer is back when the ring has
     // been requested.  (Nothing with side effects may stand before it, or hipcc makes it a vector load.)
     int kv_now = 0;
@@ -179,18 +200,18 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = hp.M;
     const int ksteps = hp.K >> 5;
-    const int nchunks = (ksteps + LSK_KC_STEPS - 1) / LSK_KC_STEPS;
+    const int nchunks = (ksteps + KC_STEPS - 1) / KC_STEPS;
     const int tile0 = block_id * hp.tiles_per_wg;
     const int ntl = min(hp.tiles_per_wg, hp.n_tiles - tile0);
     const int units = nchunks * ntl;
-    const int xstride = lsk_gemm_xstride(hp.K);
+    const int xstride = lsk_gemm_xstride(hp.K, NW);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hp.wp, 0, hp.wp_bytes, 0x00020000);
     const int c16 = lane & 15;
     const int rg = lane >> 4;
     // lm_head launches whose K fits one chunk may own MORE than 8 tiles (a 128 256-entry vocabulary is 8 016 tiles: 1 002 workgroups of
     // 8 ran as four rounds on the 256 CUs, each with its own ramp and tail): tile tl then belongs to wave tl % 8 and is finished --
     // rounded, compared -- the moment its only unit has been reduced (lsk_head_tile below)
-    const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : (ntl < LSK_WAVES ? ntl : LSK_WAVES);
+    const int n_owned = (EPI == EPI_SWIGLU) ? (ntl >> 1) : (ntl < WAVES ? ntl : WAVES);
     const bool is_owner = w < n_owned;
 
     // ---- epilogue operands: everything the owner waves will need after the last MFMA that does not depend on the product
@@ -218,7 +239,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
     }
 
     // ---- activations next (they must not queue behind the weight ring), then fill the ring ----
-    UnitInfo cur = lsk_unit_info(0, units, ntl, ksteps, tile0, w, lane);
+    UnitInfo cur = lsk_unit_info<NW>(0, units, ntl, ksteps, tile0, w, lane);
     LSK_TRACE_POINT(9);                                           // address arithmetic done, nothing requested yet
     elem8 xr[MB];
     elem8 nw = {};
@@ -242,12 +263,12 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
         float ss2[MB];
 #pragma unroll
         for (int i = 0; i < MB; ++i) { ss[i] = 0.f; ss2[i] = 0.f; }
-        if (w < LSK_WAVES / 2) {
+        if (w < WAVES / 2) {
             // unconditional loads from clamped (always valid) slices: behind a lane predicate hipcc closes the region with a register
             // copy of a loaded value, i.e. a wait for the rows IN FRONT of the ring (ISA: s_waitcnt vmcnt(2); v_mov)
             {
                 const int k0 = min(tid * 8, cur.steps_c * 32 - 8);
-                const int k1 = min((tid + LSK_THREADS / 2) * 8, cur.steps_c * 32 - 8);
+                const int k1 = min((tid + THREADS / 2) * 8, cur.steps_c * 32 - 8);
                 nw = *(const elem8*)(hp.norm_w + k0);
                 nw2 = *(const elem8*)(hp.norm_w + k1);
 #pragma unroll
@@ -261,28 +282,28 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
                 ring[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2 /* nt */);
             }
             lsk_accumulate_squares<MB>(xr, tid * 8 < cur.steps_c * 32, ss);
-            lsk_accumulate_squares<MB>(xr2, (tid + LSK_THREADS / 2) * 8 < cur.steps_c * 32, ss2);
+            lsk_accumulate_squares<MB>(xr2, (tid + THREADS / 2) * 8 < cur.steps_c * 32, ss2);
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const float t = wave_sum(ss[i]);
                 const float t2 = wave_sum(ss2[i]);
-                if (lane == 0 && i < M) { red[i * LSK_WAVES + w] = t; red[i * LSK_WAVES + w + LSK_WAVES / 2] = t2; }
+                if (lane == 0 && i < M) { red[i * WAVES + w] = t; red[i * WAVES + w + WAVES / 2] = t2; }
             }
         }
         __syncthreads();
-        if (w < LSK_WAVES / 2) {
+        if (w < WAVES / 2) {
             float my_inv = 0.f;
             if (lane < MB) {
                 float t = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < LSK_WAVES; ++ww) t += red[lane * LSK_WAVES + ww];
+                for (int ww = 0; ww < WAVES; ++ww) t += red[lane * WAVES + ww];
                 my_inv = 1.0f / sqrtf(t / (float)hp.K + hp.eps);
             }
 #pragma unroll
             for (int i = 0; i < MB; ++i)
                 sv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_inv), i));
             lsk_store_chunk<PRO, MB>(hp, xs, xstride, sv, cur.steps_c, tid, xr, nw);
-            lsk_store_chunk<PRO, MB>(hp, xs, xstride, sv, cur.steps_c, tid + LSK_THREADS / 2, xr2, nw2);
+            lsk_store_chunk<PRO, MB>(hp, xs, xstride, sv, cur.steps_c, tid + THREADS / 2, xr2, nw2);
         } else {
 #pragma unroll
             for (int s = 0; s < LSK_SPW; ++s) {
@@ -297,16 +318,16 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
         for (int i = 0; i < MB; ++i) ss[i] = 0.f;
         // RMSNorm statistics need whole rows: walk the K-chunks last-to-first so chunk 0 stays in xr
         for (int c = nchunks - 1; c >= 1; --c) {
-            const int steps_c = min(LSK_KC_STEPS, ksteps - c * LSK_KC_STEPS);
-            lsk_load_chunk<PRO, MB>(hp, c, steps_c, tid, xr, nw);
+            const int steps_c = min(KC_STEPS, ksteps - c * KC_STEPS);
+            lsk_load_chunk<PRO, MB, NW>(hp, c, steps_c, tid, xr, nw);
             lsk_accumulate_squares<MB>(xr, tid * 8 < steps_c * 32, ss);
         }
         // chunk 0 is only REQUESTED here: the weight ring is queued right behind it, so the first HBM round trip of the
         // stream overlaps the round trip of the rows instead of following it (a wave's loads retire in order: the rows
         // arrive first, the statistics below run under the ring's flight time)
-        lsk_load_chunk<PRO, MB>(hp, 0, cur.steps_c, tid, xr, nw);
+        lsk_load_chunk<PRO, MB, NW>(hp, 0, cur.steps_c, tid, xr, nw);
     } else {
-        lsk_load_chunk<PRO, MB>(hp, 0, cur.steps_c, tid, xr, nw);
+        lsk_load_chunk<PRO, MB, NW>(hp, 0, cur.steps_c, tid, xr, nw);
     }
 #pragma unroll
     for (int s = 0; s < LSK_SPW; ++s) {
@@ -320,7 +341,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const float t = wave_sum(ss[i]);
-            if (lane == 0 && i < M) red[i * LSK_WAVES + w] = t;
+            if (lane == 0 && i < M) red[i * WAVES + w] = t;
         }
         __syncthreads();
         // every wave finishes the statistics for itself: lane i adds row i's 8 per-wave partials in wave order and
@@ -329,7 +350,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
         if (lane < MB) {
             float t = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < LSK_WAVES; ++ww) t += red[lane * LSK_WAVES + ww];
+            for (int ww = 0; ww < WAVES; ++ww) t += red[lane * WAVES + ww];
             my_inv = 1.0f / sqrtf(t / (float)hp.K + hp.eps);
         }
 #pragma unroll
@@ -345,7 +366,7 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
     LSK_TRACE_POINT(2);                                           // rows arrived, normalised, staged
     // prefetch of chunk 1's rows: BEHIND the barrier -- in front of it the requests waited in the CU's address queue behind the eight
     // waves' ring fills and held the whole workgroup at the barrier with them (down_proj of a verify pass: rows staged 1.4 us earlier)
-    if (nchunks > 1) lsk_load_chunk<PRO, MB>(hp, 1, min(LSK_KC_STEPS, ksteps - LSK_KC_STEPS), tid, xr, nw);
+    if (nchunks > 1) lsk_load_chunk<PRO, MB, NW>(hp, 1, min(KC_STEPS, ksteps - KC_STEPS), tid, xr, nw);
     // (q/k/v: the block's fields the operand addresses need are read in ONE scalar clause -- hipcc issues it at the top of the kernel,
     // the pin only keeps it from sinking the reads to their uses, one dependent round trip each)
     if (EPI == EPI_QKV) asm volatile("" : : "s"(kv_now), "s"(p.pos_off), "s"(p.rope_cos), "s"(p.rope_sin), "s"(p.block_table), "s"(p.page_size),
@@ -382,13 +403,13 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
     for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const elem8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
 
     for (int u = 0; u < units; ++u) {
-        const UnitInfo nxt = lsk_unit_info(u + 1, units, ntl, ksteps, tile0, w, lane);
+        const UnitInfo nxt = lsk_unit_info<NW>(u + 1, units, ntl, ksteps, tile0, w, lane);
         if (nchunks > 1 && cur.tl == 0 && u > 0) {
             // every wave passed the previous unit's barrier => nobody still reads the old chunk; the rows
             // of this chunk were prefetched into xr one chunk ago, the next chunk's are requested now
             lsk_store_chunk<PRO, MB>(hp, xs, xstride, sv, cur.steps_c, tid, xr, nw);
             if (cur.c + 1 < nchunks)
-                lsk_load_chunk<PRO, MB>(hp, cur.c + 1, min(LSK_KC_STEPS, ksteps - (cur.c + 1) * LSK_KC_STEPS), tid, xr, nw);
+                lsk_load_chunk<PRO, MB, NW>(hp, cur.c + 1, min(KC_STEPS, ksteps - (cur.c + 1) * KC_STEPS), tid, xr, nw);
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < LSK_SPW; ++s) afr[s] = *(const elem8*)(xa + min(cur.ks0 + s, cur.steps_c - 1) * 64);
@@ -407,15 +428,15 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
             //  "consume s -> refill s" with sched_barrier(0) gives the textbook vmcnt(15) stream but measured
             //  0..-4 % on every shape -- the HBM pipe is already full at ~8 KiB per wave in flight)
         }
-        float* sl = slab + ((u & 1) * LSK_WAVES + w) * 256;
+        float* sl = slab + ((u & 1) * WAVES + w) * 256;
         *(f32x4*)(sl + lane * 4) = acc;
         __syncthreads();
-        const int owner = (EPI == EPI_SWIGLU) ? (cur.tl >> 1) : (EPI == EPI_HEAD ? (cur.tl & (LSK_WAVES - 1)) : cur.tl);
+        const int owner = (EPI == EPI_SWIGLU) ? (cur.tl >> 1) : (EPI == EPI_HEAD ? (cur.tl & (WAVES - 1)) : cur.tl);
         if (w == owner) {
-            const float* sb = slab + (u & 1) * LSK_WAVES * 256 + lane * 4;
+            const float* sb = slab + (u & 1) * WAVES * 256 + lane * 4;
             f32x4 t = *(const f32x4*)sb;
 #pragma unroll
-            for (int ww = 1; ww < LSK_WAVES; ++ww) t += *(const f32x4*)(sb + ww * 256);
+            for (int ww = 1; ww < WAVES; ++ww) t += *(const f32x4*)(sb + ww * 256);
             if (EPI == EPI_HEAD && nchunks == 1) lsk_head_tile(p, t, (tile0 + cur.tl) * 16 + c16, hp.N, M, rg, rbv, rbi);
             else if (EPI == EPI_SWIGLU && (cur.tl & 1)) own1 += t;
             else own0 += t;
@@ -533,8 +554,8 @@ __device__ __forceinline__ void lsk_gemm_body(const GemmHot& hp, const GemmParam
 #endif
 }
 
-template <int PRO, int EPI, int MB>
-__global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const elem_t* x, const elem_t* wp, const void* a2, const void* a3, int ldx, int K,
+template <int PRO, int EPI, int MB, int NW>
+__global__ __launch_bounds__(NW * 64) void lsk_gemm_kernel(const elem_t* x, const elem_t* wp, const void* a2, const void* a3, int ldx, int K,
                                                                unsigned wp_bytes, int N, int m_tpw, unsigned e0, const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GemmHot hp;
@@ -545,7 +566,7 @@ __global__ __launch_bounds__(LSK_THREADS) void lsk_gemm_kernel(const elem_t* x, 
     hp.h = (EPI == EPI_RESID) ? (elem_t*)const_cast<void*>(a2) : nullptr;
     hp.ldh = (EPI == EPI_RESID) ? (int)e0 : 0;
     hp.kv_len = (EPI == EPI_QKV) ? (const int*)a3 : nullptr;
-    lsk_gemm_body<PRO, EPI, MB>(hp, p, blockIdx.x, smem);
+    lsk_gemm_body<PRO, EPI, MB, NW>(hp, p, blockIdx.x, smem);
 }
 
 // the explicit-argument list of a launch, from the block (host side)

@@ -16,13 +16,20 @@ static const size_t kMaxGemmLds = 160 * 1024;
 #define LSK_MB_9 10
 #define LSK_MB_11 13
 
+template <int PRO, int EPI, int NW>
+static int set_gemm_attr_nw() {
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_MID, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_9, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_11, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 16, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    return 0;
+}
+
 template <int PRO, int EPI>
 static int set_gemm_attr() {
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, LSK_MB_11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
-    HIP_OK(hipFuncSetAttribute((const void*)lsk_gemm_kernel<PRO, EPI, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGemmLds));
+    LSK_TRY((set_gemm_attr_nw<PRO, EPI, 4>()));
+    LSK_TRY((set_gemm_attr_nw<PRO, EPI, 8>()));
     return 0;
 }
 
@@ -62,32 +69,31 @@ static LskTrace lsk_trace_next(int kind, int sub, int m, int grid) {
 }
 #endif
 
-static int tiles_per_wg(int n_units, int target_wgs, int max_units = 8) {   // units = tiles (or gate/up pairs)
+static int tiles_per_wg(int n_units, int target_wgs, int max_units) {   // units = tiles (or gate/up pairs)
     int t = (n_units + target_wgs - 1) / target_wgs;
     return t < 1 ? 1 : (t > max_units ? max_units : t);
 }
 
-template <int PRO, int EPI, int MB>
+template <int PRO, int EPI, int MB, int NW>
 static void launch_gemm_mb(const GemmParams& p, int grid, size_t lds, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     // the fields a workgroup needs before its first weight request ride in front of the block (GemmHot, lsk_gemm.h)
     const GemmHotArgs<PRO, EPI> a(p);
-    if (ev_start != nullptr) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB>), dim3(grid), dim3(LSK_THREADS), lds, st, ev_start, ev_stop, 0,
+    if (ev_start != nullptr) hipExtLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB, NW>), dim3(grid), dim3(NW * 64), lds, st, ev_start, ev_stop, 0,
                                                    p.x, p.wp, a.a2, a.a3, p.ldx, p.K, p.wp_bytes, p.N, a.m_tpw, a.e0, p);
-    else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB>), dim3(grid), dim3(LSK_THREADS), lds, st,
+    else hipLaunchKernelGGL((lsk_gemm_kernel<PRO, EPI, MB, NW>), dim3(grid), dim3(NW * 64), lds, st,
                             p.x, p.wp, a.a2, a.a3, p.ldx, p.K, p.wp_bytes, p.N, a.m_tpw, a.e0, p);
 }
 
-template <int PRO, int EPI>
-static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_out = nullptr, hipEvent_t ev_start = nullptr,
-                       hipEvent_t ev_stop = nullptr) {
+template <int PRO, int EPI, int NW>
+static int launch_gemm_nw(GemmParams& p, int target_wgs, hipStream_t st, int* grid_out, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int unit = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int n_units = p.n_tiles / unit;
-    // a wave keeps one accumulator per owned tile across the K-chunks: <= 8 tiles (gate/up pairs) per workgroup -- except for the
+    // a wave keeps one accumulator per owned tile across the K-chunks: <= NW tiles (gate/up pairs) per workgroup -- except for the
     // lm_head when K is a single chunk, where a tile is finished as soon as its unit is (lsk_head_tile): any number
-    const int max_units = (EPI == EPI_HEAD && p.K <= LSK_KC_ELEMS) ? (1 << 20) : 8;
+    const int max_units = (EPI == EPI_HEAD && p.K <= lsk_kc_elems(NW)) ? (1 << 20) : NW;
     p.tiles_per_wg = tiles_per_wg(n_units, target_wgs, max_units) * unit;
     const int grid = (p.n_tiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
-    const size_t lds = lsk_gemm_lds_bytes(p.M, p.K);
+    const size_t lds = lsk_gemm_lds_bytes(p.M, p.K, NW);
     if (p.n_tiles != (p.N + 15) / 16) return lsk_fail("gemm: n_tiles %d is not ceil(N / 16) of N = %d", p.n_tiles, p.N);   // the kernel derives it
     if (lds > kMaxGemmLds) return lsk_fail("gemm LDS %zu exceeds %zu", lds, kMaxGemmLds);
     // 32-bit buffer offsets; the out-of-range sentinel of ragged ring slots must stay beyond the descriptor's range
@@ -96,14 +102,22 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
     p.trace = lsk_trace_next(0, (PRO * 16 + EPI) | (p.K << 8), p.M, grid);
 #endif
     // profiling (ev_start != nullptr): the events are bound to THIS dispatch's own begin / end timestamps (what rocprofv3 reports)
-    if (p.M == 1) launch_gemm_mb<PRO, EPI, 1>(p, grid, lds, st, ev_start, ev_stop);
-    else if (p.M <= LSK_MB_MID) launch_gemm_mb<PRO, EPI, LSK_MB_MID>(p, grid, lds, st, ev_start, ev_stop);
-    else if (p.M <= LSK_MB_9) launch_gemm_mb<PRO, EPI, LSK_MB_9>(p, grid, lds, st, ev_start, ev_stop);
-    else if (p.M <= LSK_MB_11) launch_gemm_mb<PRO, EPI, LSK_MB_11>(p, grid, lds, st, ev_start, ev_stop);
-    else launch_gemm_mb<PRO, EPI, 16>(p, grid, lds, st, ev_start, ev_stop);
+    if (p.M == 1) launch_gemm_mb<PRO, EPI, 1, NW>(p, grid, lds, st, ev_start, ev_stop);
+    else if (p.M <= LSK_MB_MID) launch_gemm_mb<PRO, EPI, LSK_MB_MID, NW>(p, grid, lds, st, ev_start, ev_stop);
+    else if (p.M <= LSK_MB_9) launch_gemm_mb<PRO, EPI, LSK_MB_9, NW>(p, grid, lds, st, ev_start, ev_stop);
+    else if (p.M <= LSK_MB_11) launch_gemm_mb<PRO, EPI, LSK_MB_11, NW>(p, grid, lds, st, ev_start, ev_stop);
+    else launch_gemm_mb<PRO, EPI, 16, NW>(p, grid, lds, st, ev_start, ev_stop);
     HIP_OK(hipGetLastError());
     if (grid_out) *grid_out = grid;
     return 0;
+}
+
+// the projection launch: four or eight waves per workgroup by (kernel, K) -- lsk_gemm_waves, lsk_gemm.h
+template <int PRO, int EPI>
+static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_out = nullptr, hipEvent_t ev_start = nullptr,
+                       hipEvent_t ev_stop = nullptr) {
+    if (lsk_gemm_waves(PRO, EPI, p.K) == 4) return launch_gemm_nw<PRO, EPI, 4>(p, target_wgs, st, grid_out, ev_start, ev_stop);
+    return launch_gemm_nw<PRO, EPI, 8>(p, target_wgs, st, grid_out, ev_start, ev_stop);
 }
 
 #ifndef LSK_PF_RT
