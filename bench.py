@@ -312,7 +312,7 @@ def replica_bench(args, cfg, E, S, rank, world, dev, backend, full):
         traffic, source = None, None
         for cand in ("r06_pmc_gateup.json", "r05_pmc_gateup.json", "r04_pmc_gateup.json", "r03_pmc_gateup.json", "r02_pmc_gateup.json", "r01_pmc_gateup.json"):
             pmc = os.path.join(ROOT, "profiles", cand)
-            if args.model == "llama2-7B" and rows == 511 and os.path.exists(pmc):      # (the PMC pass is the default workload's: a 512-token prompt)
+            if args.model == "llama2-7B" and os.path.exists(pmc):
                 # HBM bytes per launch need the PMC passes (rocprofv3 --pmc, separate runs): not collectable inside this run
                 traffic = json.load(open(pmc))["hbm_read_bytes_per_launch"]
                 source = f"REPLAYED from profiles/{cand} (rocprofv3 --pmc FETCH_SIZE pass of this kernel, x2 gfx950 correction); not measured by this run"
