@@ -105,6 +105,27 @@ def test_skinny_gemm_row_invariance(gpu_device):
         assert torch.equal(ym, y16[:m]), m
 
 
+@pytest.mark.parametrize("k", [2048, 4096, 5120, 8192, 1408])
+def test_skinny_gemm_row_invariance_with_the_rmsnorm_prologue(gpu_device, k):
+    """The RMSNorm-fused launches at every wave count / chunking `lsk_gemm_waves` can pick (csrc/lsk_gemm.h: four waves and 2048-feature
+    chunks at K <= 2048 and K > 4096 -- one, three and four chunks here, one of them ragged --, eight waves and ONE 4096-feature chunk at
+    K = 4096, where 2..8 rows take the split prologue and 1 / 9+ rows do not): the wave count is a function of the projection and K, never
+    of the row count, so row r of every row template has the bits of the same row passed alone, whatever the grid."""
+    g = torch.Generator().manual_seed(31 + k)
+    n = 272
+    x16 = torch.randn(16, k, generator=g).to(torch.bfloat16).to(gpu_device)
+    w = (torch.randn(n, k, generator=g) * 0.02).to(torch.bfloat16).to(gpu_device)
+    gain = (1 + 0.1 * torch.randn(k, generator=g)).to(torch.bfloat16).to(gpu_device)
+    wp = _pack(w)
+    y16 = _gemm(x16, wp, n, norm_w=gain)
+    assert torch.isfinite(y16).all()
+    for r in (0, 7, 15):
+        assert torch.equal(_gemm(x16[r:r + 1].contiguous(), wp, n, norm_w=gain)[0], y16[r]), r
+    for m in (2, 7, 8, 9, 10, 13):
+        assert torch.equal(_gemm(x16[:m].contiguous(), wp, n, norm_w=gain), y16[:m]), m
+    assert torch.equal(_gemm(x16[:7].contiguous(), wp, n, norm_w=gain, target_wgs=5), y16[:7])
+
+
 @pytest.mark.parametrize("drafts,verified,eos,expect", [
     ([5, 6, 7, 8], [5, 6, 9, 8, 1], [], (2, 4)),
     ([5, 6, 7, 8], [5, 6, 7, 8, 1], [], (4, 4)),
