@@ -529,14 +529,13 @@ int lsk_embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, elem_t* dst,
 
 // Prefill tile shapes (lsk_gemm_big.h): NTW 16-column tiles per wave x MT 16-row tiles per workgroup x NW waves, weight ring PB
 // K-tiles deep, KS K-split groups per workgroup, TR = transposed product (8-byte epilogue accesses).  Chosen per projection and prompt
-// length from kernel times at 511 and 2047 rows (tools/gemm_big_bench.hip, profiles/r06_gemm_big_bench.txt):
+// length from kernel times at 127 .. 4095 rows (tools/gemm_big_bench.hip, profiles/r06_gemm_big_bench*.txt):
 //   gate/up     : 128 x 128 tile, ring 2 (164 registers: three waves per SIMD; ring 4 holds two); NOT transposed (the SwiGLU epilogue
-//                 is a quarter of q/k/v's stores and the swapped operand order measures 4 % slower in the main loop);
-//   q/k/v       : transposed; 64-row tiles up to 1024 rows (a 512-row prompt gives 768 workgroups, one full round at three per CU),
-//                 128 x 128 above (2047 rows: 259 us against 287 for the 8-wave 64 x 256 form of rounds 2-5);
-//   o_proj/down : N = hidden gives 256 workgroups of 64 x 128 for 256 CUs at 512 rows -- one 4-wave workgroup per CU, one wave per
-//                 SIMD: K-split 2 (eight waves per workgroup, the two halves of K side by side: o_proj 26.9 -> 22.6 us, down 73.9 ->
-//                 67.8); the 128 x 128 tile once that already gives two workgroups per CU.
+//                 is a quarter of q/k/v's stores and the swapped operand order measures 4 % slower in the main loop); the best or within
+//                 2 % of it at every prompt length from 383 rows on;
+//   q/k/v       : transposed; 64 x 128 -> 64 x 192 -> 128 x 192 -> 128 x 256 (eight waves) as the prompt grows (launch_big_qkv);
+//   o_proj/down : K-split 2 with 32- / 64- / 128-row tiles while that is <= one workgroup per CU, 128 x 256 (eight waves) or 128 x 128
+//                 above (launch_big_resid).
 template <int EPI, int NTW, int MT, int PB, int NW, bool PIN, int KS, bool TR>
 static int launch_big_pb(BigGemmParams& p, hipStream_t st) {
     const int rb = (p.M + MT * 16 - 1) / (MT * 16);                        // row blocks
@@ -551,22 +550,47 @@ static int launch_big_pb(BigGemmParams& p, hipStream_t st) {
 template <int EPI, int NTW, int MT, int PBMAX, int NW, bool PIN, int KS = 1, bool TR = true>
 static int launch_big(BigGemmParams& p, hipStream_t st) {
     const int nkt = p.K / LSK_BIG_BK / KS;
-    if (PBMAX == 4 && nkt % 4 == 0) return launch_big_pb<EPI, NTW, MT, 4, NW, PIN, KS, TR>(p, st);
+    if constexpr (PBMAX == 4) {          // (constexpr: a ring-4 form of a ring-2 shape must not even be instantiated -- some would spill)
+        if (nkt % 4 == 0) return launch_big_pb<EPI, NTW, MT, 4, NW, PIN, KS, TR>(p, st);
+    }
     return launch_big_pb<EPI, NTW, MT, 2, NW, PIN, KS, TR>(p, st);
 }
 
+// Tile shape per launch from the WORKGROUP COUNTS each shape would give (round 6, second pass: tools/gemm_big_bench.hip with
+// LSK_BENCH_EXPLORE=1 at 127 .. 4095 rows, profiles/r06_gemm_big_bench_explore.txt).  A CU sustains ~3.5 TFLOP/s on these kernels once it
+// holds two waves per SIMD, whatever the tile, so the choice is about balance: the biggest tile that still gives every CU work, and never a
+// count that leaves half the chip a second round to itself (128 x 256 at 1023 rows of a 12 288-feature q/k/v: 384 workgroups at one per
+// CU, 133 us against 114 for 512 workgroups of 128 x 192).
 static int launch_big_qkv(BigGemmParams& p, hipStream_t st) {
-    return p.M > 1024 ? launch_big<EPI_QKV, 2, 8, 2, 4, false>(p, st) : launch_big<EPI_QKV, 2, 4, 2, 4, false>(p, st);
+    const int rb128 = (p.M + 127) / 128, rb64 = (p.M + 63) / 64;
+    const int w256 = rb128 * ((p.n_tiles + 15) / 16);                  // 128 x 256, eight waves: one workgroup per CU at a time
+    const int p192 = (p.n_tiles + 11) / 12;
+    if (w256 >= 448) return launch_big<EPI_QKV, 2, 8, 2, 8, false>(p, st);           // >= 1.75 rounds: 2047 rows 260.6 -> 235.3 us (llama2-7B)
+    if (rb128 * p192 >= 192) return launch_big<EPI_QKV, 3, 8, 2, 4, false>(p, st);   // 128 x 192: 511 rows 75.6 -> 71.2, 1023 rows 147.1 -> 114.5
+    if (rb64 * p192 >= 256) return launch_big<EPI_QKV, 3, 4, 2, 4, false>(p, st);    // 64 x 192: 255 rows 54.4 -> 46.9
+    return launch_big<EPI_QKV, 2, 4, 2, 4, false>(p, st);                            // 64 x 128
 }
 
 static int launch_big_gateup(BigGemmParams& p, hipStream_t st) { return launch_big<EPI_SWIGLU, 2, 8, 2, 4, false, 1, false>(p, st); }
 
 static int launch_big_resid(BigGemmParams& p, hipStream_t st) {
     const int panels = (p.n_tiles + 7) / 8;
-    if (((p.M + 127) / 128) * panels >= 512) return launch_big<EPI_RESID, 2, 8, 2, 4, false>(p, st);
-    // 64-row tiles; K-split 2 while that still leaves the chip at <= 1.5 four-wave workgroups per CU (the two groups need an even
-    // number of ring-depth-2 K-tile pairs each: K a multiple of 256)
-    if (((p.M + 63) / 64) * panels <= 384 && (p.K / LSK_BIG_BK) % 4 == 0) return launch_big<EPI_RESID, 2, 4, 2, 4, true, 2>(p, st);
+    const int rb128 = (p.M + 127) / 128;
+    // N = hidden is few panels: while a shape gives <= one workgroup per CU, K-split 2 (eight waves per workgroup, the two halves of K side
+    // by side: two waves per SIMD instead of one) with the SMALLEST row tile that still does -- 32 rows up to 255 prompt rows of a
+    // 4096-wide model (down 67.5 -> 58.2 us), 64 up to 511 (round 6, first pass), 128 up to 1023 (down 135.5 -> 106.3).  The two groups
+    // need an even number of ring-depth-2 K-tile pairs each: K a multiple of 256.
+    if ((p.K / LSK_BIG_BK) % 4 == 0) {
+        if (((p.M + 31) / 32) * panels <= 256) return launch_big<EPI_RESID, 2, 2, 2, 4, false, 2>(p, st);
+        if (((p.M + 63) / 64) * panels <= 256) return launch_big<EPI_RESID, 2, 4, 2, 4, true, 2>(p, st);
+        if (rb128 * panels <= 256) return launch_big<EPI_RESID, 2, 8, 2, 4, false, 2>(p, st);
+    }
+    // beyond that 128 x 256 tiles of eight waves (pinned activation requests) wherever their count is at most one round or at least two
+    // (2047 rows: o_proj 72.6 -> 65.0 us, down 218.9 -> 183.1), 128 x 128 in between (3071 rows: 384 of them would leave half the chip a
+    // second round)
+    const int w256 = rb128 * ((p.n_tiles + 15) / 16);
+    if (rb128 * panels > 256 && (w256 <= 256 || w256 >= 512)) return launch_big<EPI_RESID, 2, 8, 2, 8, true>(p, st);
+    if (rb128 * panels >= 512) return launch_big<EPI_RESID, 2, 8, 2, 4, false>(p, st);
     return launch_big<EPI_RESID, 2, 4, 4, 4, true>(p, st);
 }
 

@@ -82,8 +82,9 @@ __global__ __launch_bounds__(NW * KS * 64, 2) void lsk_gemm_big_kernel(const Big
     static_assert(MT == 2 || MT == 4 || MT == 8, "row tiles per workgroup");
     static_assert(PB >= 2 && PB % 2 == 0, "weight ring depth (K-tiles in flight per wave): even");
     static_assert(KS == 1 || KS == 2, "K-split groups per workgroup");
-    static_assert(KS == 1 || NW * MT * NTW * 1024 <= KS * 2 * BM * LSK_BIG_LDA, "the accumulator hand-off reuses the activation images");
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[KS * 2 * BM * LSK_BIG_LDA];
+    constexpr int IMG_BYTES = KS * 2 * BM * LSK_BIG_LDA;                         // the activation images of all groups
+    constexpr int XCH_BYTES = KS == 1 ? 0 : NW * MT * NTW * 1024;                // the accumulator hand-off reuses them
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[IMG_BYTES > XCH_BYTES ? IMG_BYTES : XCH_BYTES];
     const int tid = (KS == 1) ? threadIdx.x : (threadIdx.x & (NW * 64 - 1));      // thread inside its K-split group
     const int lane = tid & 63;
     const int grp = (KS == 1) ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x / (NW * 64));

@@ -151,6 +151,16 @@ int main(int argc, char** argv) {
             run_cfg<EPI_QKV, 2, 4, 4, 4, false, 1>("64 x 128, ring 4", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
             run_cfg<EPI_QKV, 2, 4, 2, 8, false, 1>("64 x 256 (8 waves), ring 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
             run_cfg<EPI_QKV, 2, 4, 2, 4, false, 2>("64 x 128, ring 2, K-split 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+            if (getenv("LSK_BENCH_EXPLORE")) {      // tile shapes that are not in the engine (three 16-column tiles per wave: 192-column workgroup tiles)
+                run_cfg<EPI_QKV, 3, 8, 2, 4, false, 1>("128 x 192, ring 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 3, 8, 2, 4, false, 2>("128 x 192, ring 2, K-split 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 3, 4, 2, 4, false, 1>("64 x 192, ring 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 3, 4, 2, 4, false, 2>("64 x 192, ring 2, K-split 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 4, 4, 2, 4, false, 1>("64 x 256 (4 waves), ring 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 4, 4, 2, 4, false, 2>("64 x 256 (4 waves), ring 2, K-split 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 2, 8, 2, 8, false, 1>("128 x 256 (8 waves), ring 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 2, 8, 4, 4, false, 1>("128 x 128, ring 4", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+            }
         }
         {   // ---- gate/up ----
             BigGemmParams p{};
@@ -161,6 +171,12 @@ int main(int argc, char** argv) {
             run_cfg<EPI_SWIGLU, 2, 8, 2, 4, false, 1, false>("128 x 128, ring 2, row-per-register (engine)", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
             run_cfg<EPI_SWIGLU, 2, 8, 2, 4, false, 1, true>("128 x 128, ring 2, transposed", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
             run_cfg<EPI_SWIGLU, 2, 8, 2, 4, false, 2, false>("128 x 128, ring 2, K-split 2", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
+            if (getenv("LSK_BENCH_EXPLORE")) {
+                run_cfg<EPI_SWIGLU, 2, 8, 2, 8, false, 1, false>("128 x 256 (8 waves), ring 2", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
+                run_cfg<EPI_SWIGLU, 2, 8, 2, 8, false, 1, true>("128 x 256 (8 waves), ring 2, transposed", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
+                run_cfg<EPI_SWIGLU, 4, 4, 2, 4, false, 1, false>("64 x 256 (4 waves), ring 2", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
+                run_cfg<EPI_SWIGLU, 2, 8, 4, 4, false, 1, false>("128 x 128, ring 4", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
+            }
         }
         for (int which = 0; which < 2; ++which) {   // ---- o_proj, down ----
             BigGemmParams p{};
@@ -175,6 +191,15 @@ int main(int argc, char** argv) {
             run_cfg<EPI_RESID, 2, 4, 4, 4, true, 2>("64 x 128, ring 4, pinned, K-split 2", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
             run_cfg<EPI_RESID, 2, 8, 2, 4, false, 2>("128 x 128, ring 2, K-split 2", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
             run_cfg<EPI_RESID, 2, 2, 2, 4, false, 2>("32 x 128, ring 2, K-split 2", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+            if (getenv("LSK_BENCH_EXPLORE")) {
+                run_cfg<EPI_RESID, 2, 8, 2, 8, false, 1>("128 x 256 (8 waves), ring 2", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+                run_cfg<EPI_RESID, 2, 8, 2, 8, true, 1>("128 x 256 (8 waves), ring 2, pinned", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+                run_cfg<EPI_RESID, 2, 4, 2, 8, true, 1>("64 x 256 (8 waves), ring 2, pinned", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+                run_cfg<EPI_RESID, 2, 8, 4, 4, false, 1>("128 x 128, ring 4", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+                run_cfg<EPI_RESID, 2, 8, 2, 4, true, 1>("128 x 128, ring 2, pinned", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+                run_cfg<EPI_RESID, 4, 4, 2, 4, true, 1>("64 x 256 (4 waves), ring 2, pinned", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+                run_cfg<EPI_RESID, 4, 4, 2, 4, true, 2>("64 x 256 (4 waves), ring 2, pinned, K-split 2", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+            }
         }
     }
     return 0;
