@@ -533,7 +533,8 @@ int lsk_embed_rows_dev(lsk_engine* e, const int* tokens_dev, int n, elem_t* dst,
 //   gate/up     : 128 x 128 tile, ring 2 (164 registers: three waves per SIMD; ring 4 holds two); NOT transposed (the SwiGLU epilogue
 //                 is a quarter of q/k/v's stores and the swapped operand order measures 4 % slower in the main loop); the best or within
 //                 2 % of it at every prompt length from 383 rows on;
-//   q/k/v       : transposed; 64 x 128 -> 64 x 192 -> 128 x 192 -> 128 x 256 (eight waves) as the prompt grows (launch_big_qkv);
+//   q/k/v       : transposed; 64 x 128 -> 64 x 192 -> 128 x 192 -> 128 x 256 / 128 x 384 (eight waves) as the prompt grows, by a cost
+//                 model of rounds x tile area (launch_big_qkv);
 //   o_proj/down : K-split 2 with 32- / 64- / 128-row tiles while that is <= one workgroup per CU, 128 x 256 (eight waves) or 128 x 128
 //                 above (launch_big_resid).
 template <int EPI, int NTW, int MT, int PB, int NW, bool PIN, int KS, bool TR>
@@ -562,13 +563,30 @@ static int launch_big(BigGemmParams& p, hipStream_t st) {
 // count that leaves half the chip a second round to itself (128 x 256 at 1023 rows of a 12 288-feature q/k/v: 384 workgroups at one per
 // CU, 133 us against 114 for 512 workgroups of 128 x 192).
 static int launch_big_qkv(BigGemmParams& p, hipStream_t st) {
-    const int rb128 = (p.M + 127) / 128, rb64 = (p.M + 63) / 64;
-    const int w256 = rb128 * ((p.n_tiles + 15) / 16);                  // 128 x 256, eight waves: one workgroup per CU at a time
-    const int p192 = (p.n_tiles + 11) / 12;
-    if (w256 >= 448) return launch_big<EPI_QKV, 2, 8, 2, 8, false>(p, st);           // >= 1.75 rounds: 2047 rows 260.6 -> 235.3 us (llama2-7B)
-    if (rb128 * p192 >= 192) return launch_big<EPI_QKV, 3, 8, 2, 4, false>(p, st);   // 128 x 192: 511 rows 75.6 -> 71.2, 1023 rows 147.1 -> 114.5
-    if (rb64 * p192 >= 256) return launch_big<EPI_QKV, 3, 4, 2, 4, false>(p, st);    // 64 x 192: 255 rows 54.4 -> 46.9
-    return launch_big<EPI_QKV, 2, 4, 2, 4, false>(p, st);                            // 64 x 128
+    // cost of a shape = (workgroups on the busiest CU) x (tile area) / (TFLOP/s a CU sustains on that shape), the rates read off the table:
+    // ~3.7-3.8 for the eight-wave tiles, 3.45 for 128-row four-wave tiles once a CU holds two of them (2.85 alone: one wave per SIMD),
+    // 2.2-2.8 for 64-row tiles.  llama2-7B (N = 12 288): 64 x 128 up to 191 rows, 64 x 192 to 319, 128 x 192 to 639, 128 x 384 where it is
+    // whole rounds (1023 rows: 256 workgroups, 147.1 -> 102.3 us = 1 006 TFLOP/s; 2047: 512, 260.6 -> 211.0), 128 x 256 / 128 x 192 between.
+    struct Shape { int bm, tiles; float alone, shared; };
+    static const Shape shapes[5] = {{64, 8, 1.75f, 2.3f}, {64, 12, 2.15f, 2.8f}, {128, 12, 2.85f, 3.45f}, {128, 16, 3.7f, 3.7f}, {128, 24, 3.8f, 3.8f}};
+    int best = 0;
+    float best_cost = 0.f;
+    for (int i = 0; i < 5; ++i) {
+        const Shape& sh = shapes[i];
+        const int wgs = ((p.M + sh.bm - 1) / sh.bm) * ((p.n_tiles + sh.tiles - 1) / sh.tiles);
+        const int per_cu = (wgs + 255) / 256;
+        float rate = per_cu == 1 ? sh.alone : sh.shared;
+        if (i == 0 && per_cu >= 3) rate = 2.65f;
+        const float cost = (float)per_cu * (float)(sh.bm * sh.tiles) / rate;
+        if (i == 0 || cost <= best_cost) { best = i; best_cost = cost; }        // ties go to the bigger tile
+    }
+    switch (best) {
+        case 4: return launch_big<EPI_QKV, 3, 8, 2, 8, true>(p, st);
+        case 3: return launch_big<EPI_QKV, 2, 8, 2, 8, false>(p, st);
+        case 2: return launch_big<EPI_QKV, 3, 8, 2, 4, false>(p, st);
+        case 1: return launch_big<EPI_QKV, 3, 4, 2, 4, false>(p, st);
+        default: return launch_big<EPI_QKV, 2, 4, 2, 4, false>(p, st);
+    }
 }
 
 static int launch_big_gateup(BigGemmParams& p, hipStream_t st) { return launch_big<EPI_SWIGLU, 2, 8, 2, 4, false, 1, false>(p, st); }

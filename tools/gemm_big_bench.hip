@@ -160,6 +160,12 @@ int main(int argc, char** argv) {
                 run_cfg<EPI_QKV, 4, 4, 2, 4, false, 2>("64 x 256 (4 waves), ring 2, K-split 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
                 run_cfg<EPI_QKV, 2, 8, 2, 8, false, 1>("128 x 256 (8 waves), ring 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
                 run_cfg<EPI_QKV, 2, 8, 4, 4, false, 1>("128 x 128, ring 4", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 2, 8, 2, 8, true, 1>("128 x 256 (8 waves), ring 2, pinned", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 2, 8, 4, 8, false, 1>("128 x 256 (8 waves), ring 4", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 2, 8, 4, 8, true, 1>("128 x 256 (8 waves), ring 4, pinned", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 3, 8, 2, 4, true, 1>("128 x 192, ring 2, pinned", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 3, 8, 2, 8, false, 1>("128 x 384 (8 waves), ring 2", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
+                run_cfg<EPI_QKV, 3, 8, 2, 8, true, 1>("128 x 384 (8 waves), ring 2, pinned", p, b.wqkv, b.q, (size_t)M * NH * HD, nullptr, b, &first, fl);
             }
         }
         {   // ---- gate/up ----
@@ -176,6 +182,9 @@ int main(int argc, char** argv) {
                 run_cfg<EPI_SWIGLU, 2, 8, 2, 8, false, 1, true>("128 x 256 (8 waves), ring 2, transposed", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
                 run_cfg<EPI_SWIGLU, 4, 4, 2, 4, false, 1, false>("64 x 256 (4 waves), ring 2", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
                 run_cfg<EPI_SWIGLU, 2, 8, 4, 4, false, 1, false>("128 x 128, ring 4", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
+                run_cfg<EPI_SWIGLU, 2, 8, 2, 8, true, 1, false>("128 x 256 (8 waves), ring 2, pinned", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
+                run_cfg<EPI_SWIGLU, 2, 8, 4, 8, true, 1, false>("128 x 256 (8 waves), ring 4, pinned", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
+                run_cfg<EPI_SWIGLU, 2, 8, 2, 4, true, 1, false>("128 x 128, ring 2, pinned", p, b.wgu, b.act_out, (size_t)M * I, nullptr, b, &first, fl);
             }
         }
         for (int which = 0; which < 2; ++which) {   // ---- o_proj, down ----
@@ -199,6 +208,8 @@ int main(int argc, char** argv) {
                 run_cfg<EPI_RESID, 2, 8, 2, 4, true, 1>("128 x 128, ring 2, pinned", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
                 run_cfg<EPI_RESID, 4, 4, 2, 4, true, 1>("64 x 256 (4 waves), ring 2, pinned", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
                 run_cfg<EPI_RESID, 4, 4, 2, 4, true, 2>("64 x 256 (4 waves), ring 2, pinned, K-split 2", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+                run_cfg<EPI_RESID, 2, 8, 4, 8, true, 1>("128 x 256 (8 waves), ring 4, pinned", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
+                run_cfg<EPI_RESID, 3, 8, 2, 8, true, 1>("128 x 384 (8 waves), ring 2, pinned", p, which ? b.wdown : b.wo, b.h, (size_t)M * H, h0, b, &first, fl);
             }
         }
     }
