@@ -505,12 +505,17 @@ __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineP
 }
 
 // ---- prompt-prefill attention: RT x 16 query rows x all visible keys per workgroup, online softmax (flash shape) ----
-// grid = (n_heads, ceil(rows / (16 RT))), block = 4 waves.  Wave w walks KV pages w, w+4, ... of its head in 32-key
-// sub-blocks: K / V^T fragments straight from the pages (same layouts as the decode kernel), S = QK^T and
-// O += P V on MFMA, running (max, sum) per row with one rescale of O per sub-block, P rounded to bf16 through
-// LDS.  The RT row tiles of a workgroup share every K / V^T fragment a wave loads (the kernel is bound by those
-// fragment-shaped L2 reads, not by the MFMAs: RT = 2 halves them); PF selects what is requested one sub-block ahead.  The 4 waves are merged in a fixed order at the end, one row tile at a time.
-// A row's arithmetic depends only on its position (key partition by page, fixed sub-block order): a row tile for
+// grid = (n_heads, ceil(rows / (16 RT))), block = 4 waves.  Wave w walks the 32-key sub-blocks w, w+4, ... of its head: K / V^T fragments straight from the pages (same layouts as the decode kernel), running (max, sum) per row with one
+// rescale of O per sub-block.  Both products TRANSPOSED, as in the decode kernel (round 6; lsk_attn_body has the layout argument):
+// S^T = K Q^T with the K tile rows permuted in the load addresses leaves a lane with 8 CONSECUTIVE keys of ONE query row -- already the
+// B operand of O^T = V^T P^T -- so P never goes through LDS, a row's statistics are 8 in-lane values and two row swaps, the rescale
+// factor of a row tile is ONE value per lane, and the output leaves as 16-byte LDS stores.  Rounds 2-5 kept S in the C layout (one
+// query row per register), reduced every register over 16 lanes with 2 x 4 DPP steps, and rounded P through 2-byte LDS stores
+// (SQ_LDS_BANK_CONFLICT 0.23 of the LDS cycles, profiles/r06_profile_summary.md): ~400 VALU instructions per 32-key sub-block against
+// 512 cycles of MFMA -- the kernel was bound by its softmax, not by its fragments.
+// The RT row tiles of a workgroup share every K / V^T fragment a wave loads; PF selects what is requested one sub-block ahead.  The 4
+// waves are merged in a fixed order at the end, one row tile at a time.
+// A row's arithmetic depends only on its position (key partition by absolute sub-block index, fixed sub-block order): a row tile for
 // which a sub-block lies entirely in the future multiplies its accumulators by exp2(0) = 1 and adds P = 0 products,
 // so results are bit-identical for every RT.  One launch per layer replaces the rows/16 launches of the decode
 // kernel; only prompt rows that are not decision rows go through it.
@@ -531,23 +536,24 @@ struct AttnPrefillParams {
 };
 
 #ifndef LSK_PF_MINW
-#define LSK_PF_MINW 2               // min waves per SIMD: keeps hipcc inside 256 registers WITHOUT parking values in AGPRs (218 + 64 -> 222 + 0)
+#define LSK_PF_MINW 2               // min waves per SIMD: keeps hipcc inside 256 registers WITHOUT parking values in AGPRs
 #endif
 template <int HD, int RT, int PF>
 __global__ __launch_bounds__(LSK_ATTN_THREADS, LSK_PF_MINW) void lsk_attn_prefill_kernel(const AttnPrefillParams p) {
     constexpr int KS = HD / 32;
     constexpr int DT = HD / 16;
-    constexpr int PSTRIDE = HD + 2;
-    constexpr int PB_STRIDE = 80;
+    constexpr int LS = HD + 4;               // LDS row stride of the wave merge: 16-byte aligned rows, 4 modulo 64 banks
     constexpr int RB = RT * 16;              // query rows per workgroup
-    __shared__ __attribute__((aligned(16))) unsigned char pbuf[LSK_ATTN_WAVES * RB * PB_STRIDE];
-    __shared__ float sm[LSK_ATTN_WAVES * 16 * PSTRIDE];
+    __shared__ __attribute__((aligned(16))) float sm[LSK_ATTN_WAVES * 16 * LS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = blockIdx.x;
-    const int r0 = blockIdx.y * RB;
+    // causal: the LAST row block has the most keys.  Row blocks are taken in descending order of blockIdx.y so that the longest workgroups
+    // are dispatched first and the short ones fill the tail (2047 rows: 2048 workgroups on 512 slots -- in ascending order the last round
+    // was the 64-sub-block workgroups on their own)
+    const int r0 = (gridDim.y - 1 - blockIdx.y) * RB;
     const int kvh = head / p.group;
     const int c16 = lane & 15;
     const int g = lane >> 4;
@@ -556,50 +562,58 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS, LSK_PF_MINW) void lsk_attn_prefil
     const int last_key = base_pos + M - 1;
     const int n_pages = last_key / LSK_ATTN_PAGE + 1;
 
+    // Q as the B operand of S^T = K Q^T: this lane's query row is c16 of every row tile
     elem8 qa[RT][KS];
+    int lim[RT];                             // last visible key of this lane's row of tile rt; a padding row sees none
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const elem_t* qp = p.q + (size_t)(r0 + min(rt * 16 + c16, M - 1)) * p.ldq + head * HD + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qa[rt][ks] = *(const elem8*)(qp + ks * 32);
+        lim[rt] = (rt * 16 + c16 < M) ? base_pos + rt * 16 + c16 : -1;
     }
 
-    float mrun[RT][4], lrun[RT][4];
-    f32x4 o[RT][DT];
+    float mrun[RT], lrun[RT];
+    f32x4 o[RT][DT];                         // O^T: features dt*16 + g*4 + r of query row c16
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { mrun[rt][r] = LSK_ATTN_NEG; lrun[rt][r] = 0.f; }
+        mrun[rt] = LSK_ATTN_NEG;
+        lrun[rt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[rt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    unsigned char* pw = pbuf + w * RB * PB_STRIDE;
 
-    // this wave's sub-blocks, flattened: j -> page w + 4 (j / 4), 32-key sub-block j % 4; only the last page in reach is partial
-    const int my_pages = (n_pages > w) ? (n_pages - w + LSK_ATTN_WAVES - 1) / LSK_ATTN_WAVES : 0;
-    const bool own_last = my_pages > 0 && ((n_pages - 1 - w) % LSK_ATTN_WAVES == 0);
-    const int nj = my_pages * 4 - (own_last ? 3 - ((last_key - (n_pages - 1) * LSK_ATTN_PAGE) >> 5) : 0);
+    // the 32-key sub-blocks in reach are dealt to the 4 waves round robin: wave w takes sub-blocks w, w + 4, ... (sub-block s = keys
+    // [32 s, 32 s + 32) = quarter s % 4 of page s / 4).  (Rounds 1-5 dealt whole PAGES: a 512-token prompt is at most 4 pages, its first
+    // row blocks had one busy wave and three idle ones.)  A function of the absolute key index only, like the page split before it.
+    const int nsb = (last_key >> 5) + 1;
+    const int nj = (nsb > w) ? (nsb - w + LSK_ATTN_WAVES - 1) / LSK_ATTN_WAVES : 0;
     // PF = what is requested one sub-block ahead: 0 nothing, 1 the K fragments, 2 K and V^T (64 more registers at d = 128)
     elem8 kb[PF >= 1 ? 2 : 1][2][KS], vb[PF == 2 ? 2 : 1][DT];
+    // K is the A operand: tile t's row a is key (a / 4) * 8 + t * 4 + a % 4 of the sub-block, so that this lane's accumulator registers
+    // s0[r], s1[r] are keys g*8 + r, g*8 + 4 + r
+    const int krow = (c16 >> 2) * 8 + (c16 & 3);
     auto load_k = [&](int j, elem8 (&kd)[2][KS]) {      // unconditional: j is clamped by the caller
-        const int page = p.block_table[w + LSK_ATTN_WAVES * (j >> 2)];
-        const elem_t* kp = p.kpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)((j & 3) * 32 + c16) * HD + g * 8;
+        const int sb = w + LSK_ATTN_WAVES * j;
+        const int page = p.block_table[sb >> 2];
+        const elem_t* kp = p.kpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)((sb & 3) * 32 + krow) * HD + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kd[0][ks] = *(const elem8*)(kp + ks * 32);
-            kd[1][ks] = *(const elem8*)(kp + 16 * HD + ks * 32);
+            kd[1][ks] = *(const elem8*)(kp + 4 * HD + ks * 32);
         }
     };
     auto load_v = [&](int j, elem8 (&vd)[DT]) {
-        const int page = p.block_table[w + LSK_ATTN_WAVES * (j >> 2)];
-        const elem_t* vp = p.vpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)c16 * LSK_ATTN_PAGE + (j & 3) * 32 + g * 8;
+        const int sb = w + LSK_ATTN_WAVES * j;
+        const int page = p.block_table[sb >> 2];
+        const elem_t* vp = p.vpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)c16 * LSK_ATTN_PAGE + (sb & 3) * 32 + g * 8;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) vd[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
     };
     auto block = [&](int j, elem8 (&kd)[2][KS], elem8 (&vd)[DT]) {
-        const int key0 = (w + LSK_ATTN_WAVES * (j >> 2)) * LSK_ATTN_PAGE + (j & 3) * 32;
+        const int kbase = (w + LSK_ATTN_WAVES * j) * 32 + g * 8;     // first of this lane's 8 keys
         {   // never-written slots behind this block's last key may hold NaN: zero their V (see lsk_attn_body)
-            const int nvalid = last_key + 1 - (key0 + g * 8);
+            const int nvalid = last_key + 1 - kbase;
             if (nvalid < 8) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
@@ -608,52 +622,40 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS, LSK_PF_MINW) void lsk_attn_prefil
                         if (jj >= nvalid) vd[dt][jj] = (elem_t)0.0f;
             }
         }
-        const int keyA = key0 + c16;
-        float alpha[RT][4];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s0 = LSK_MFMA_16x16x32(qa[rt][ks], kd[0][ks], s0, 0, 0, 0);
-                s1 = LSK_MFMA_16x16x32(qa[rt][ks], kd[1][ks], s1, 0, 0, 0);
+                s0 = LSK_MFMA_16x16x32(kd[0][ks], qa[rt][ks], s0, 0, 0, 0);
+                s1 = LSK_MFMA_16x16x32(kd[1][ks], qa[rt][ks], s1, 0, 0, 0);
             }
+            float sc[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = rt * 16 + g * 4 + r;
-                const int lim = base_pos + row;
-                const bool ok0 = (row < M) && (keyA <= lim);
-                const bool ok1 = (row < M) && (keyA + 16 <= lim);
-                const float a0 = ok0 ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
-                const float a1 = ok1 ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
-                float m = fmaxf(a0, a1);
-                m = row16_max(m);
-                const float mn = fmaxf(mrun[rt][r], m);
-                alpha[rt][r] = __builtin_amdgcn_exp2f(mrun[rt][r] - mn);
-                const float p0 = ok0 ? __builtin_amdgcn_exp2f(a0 - mn) : 0.f;
-                const float p1 = ok1 ? __builtin_amdgcn_exp2f(a1 - mn) : 0.f;
-                float l = p0 + p1;
-                l = row16_sum(l);
-                lrun[rt][r] = lrun[rt][r] * alpha[rt][r] + l;
-                mrun[rt][r] = mn;
-                *(elem_t*)(pw + row * PB_STRIDE + c16 * 2) = f2e(p0);
-                *(elem_t*)(pw + row * PB_STRIDE + (16 + c16) * 2) = f2e(p1);
+                sc[r] = (kbase + r <= lim[rt]) ? s0[r] * p.scale_log2e : LSK_ATTN_NEG;
+                sc[4 + r] = (kbase + 4 + r <= lim[rt]) ? s1[r] * p.scale_log2e : LSK_ATTN_NEG;
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float m = col4_max(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))));
+            const float mn = fmaxf(mrun[rt], m);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[rt] - mn);
+            float pe[8];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const elem8 pa = *(const elem8*)(pw + (rt * 16 + c16) * PB_STRIDE + g * 16);
+            for (int jj = 0; jj < 8; ++jj) pe[jj] = (kbase + jj <= lim[rt]) ? __builtin_amdgcn_exp2f(sc[jj] - mn) : 0.f;
+            const float l = col4_sum(((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7])));
+            lrun[rt] = lrun[rt] * alpha + l;
+            mrun[rt] = mn;
+            // P is rounded to bf16 (as HF's eager path and torch's flash kernels both do before the second GEMM)
+            elem8 pa;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pa[jj] = f2e(pe[jj]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[rt][dt][r] *= alpha[rt][r];
-                o[rt][dt] = LSK_MFMA_16x16x32(pa, vd[dt], o[rt][dt], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) o[rt][dt][r] *= alpha;
+                o[rt][dt] = LSK_MFMA_16x16x32(vd[dt], pa, o[rt][dt], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_wave_barrier();     // P of the next sub-block must not overwrite before the reads above
     };
     if (PF == 0) {
         for (int j = 0; j < nj; ++j) {
@@ -677,39 +679,41 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS, LSK_PF_MINW) void lsk_attn_prefil
             block(j + 1, kb[K1], vb[V1]);
         }
     }
-    // ---- merge the 4 waves (fixed order), one row tile at a time through 4 x 16 x (HD + 2) floats of LDS ----
-    float* dst = sm + (size_t)w * 16 * PSTRIDE;
+    // ---- merge the 4 waves (fixed order), one row tile at a time through 4 x 16 x (HD + 4) floats of LDS ----
+    float* dst = sm + (size_t)(w * 16 + c16) * LS;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         if (rt) __syncthreads();
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(g * 4 + r) * PSTRIDE + dt * 16 + c16] = o[rt][dt][r];
-        if (c16 == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dst[(g * 4 + r) * PSTRIDE + HD] = mrun[rt][r];
-                dst[(g * 4 + r) * PSTRIDE + HD + 1] = lrun[rt][r];
-            }
+        for (int dt = 0; dt < DT; ++dt) *(f32x4*)(dst + dt * 16 + g * 4) = o[rt][dt];
+        if (g == 0) {
+            dst[HD] = mrun[rt];
+            dst[HD + 1] = lrun[rt];
         }
         __syncthreads();
         const int mt = min(16, M - rt * 16);
-        for (int e = tid; e < mt * HD; e += LSK_ATTN_THREADS) {
-            const int r = e / HD;
-            const int d = e - r * HD;
+        // four adjacent features per work item: 16-byte LDS reads, one 8-byte store
+        for (int e = tid; e < mt * (HD / 4); e += LSK_ATTN_THREADS) {
+            const int r = e / (HD / 4);
+            const int d = (e - r * (HD / 4)) * 4;
+            float f[LSK_ATTN_WAVES];
             float m = LSK_ATTN_NEG;
 #pragma unroll
-            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) m = fmaxf(m, sm[(ww * 16 + r) * PSTRIDE + HD]);
-            float a = 0.f, l = 0.f;
+            for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) { f[ww] = sm[(ww * 16 + r) * LS + HD]; m = fmaxf(m, f[ww]); }
+            float a[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
 #pragma unroll
             for (int ww = 0; ww < LSK_ATTN_WAVES; ++ww) {
-                const float* src = sm + (ww * 16 + r) * PSTRIDE;
-                const float f = __builtin_amdgcn_exp2f(src[HD] - m);
-                a += src[d] * f;
-                l += src[HD + 1] * f;
+                const float* src = sm + (ww * 16 + r) * LS;
+                const float fw = __builtin_amdgcn_exp2f(f[ww] - m);
+                const f32x4 x = *(const f32x4*)(src + d);
+                a[0] += x[0] * fw; a[1] += x[1] * fw; a[2] += x[2] * fw; a[3] += x[3] * fw;
+                l += src[HD + 1] * fw;
             }
-            p.out[(size_t)(r0 + rt * 16 + r) * p.ldo + head * HD + d] = f2e(a / l);
+            typedef elem_t elem4 __attribute__((ext_vector_type(4)));
+            elem4 ov;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ov[k] = f2e(a[k] / l);
+            *(elem4*)(p.out + (size_t)(r0 + rt * 16 + r) * p.ldo + head * HD + d) = ov;
         }
     }
 }

@@ -121,16 +121,30 @@ static int launch_gemm(GemmParams& p, int target_wgs, hipStream_t st, int* grid_
 }
 
 #ifndef LSK_PF_RT
-#define LSK_PF_RT 2               // 16-row query tiles per workgroup of the prefill attention kernel (lsk_attn.h)
+#define LSK_PF_RT 0               // 16-row query tiles per workgroup of the prefill attention kernel (lsk_attn.h); 0 = by prompt length
+#endif
+#ifndef LSK_PF_RT_LONG_ROWS
+#define LSK_PF_RT_LONG_ROWS 768   // prompts beyond this take three row tiles per workgroup
 #endif
 #ifndef LSK_PF_PREFETCH
-#define LSK_PF_PREFETCH 0         // fragments requested one 32-key sub-block ahead: 0 none, 1 K, 2 K and V^T (measured: no gain, fewer waves)
+#define LSK_PF_PREFETCH 0         // fragments requested one 32-key sub-block ahead: 0 none, 1 K, 2 K and V^T (measured: spills, slower)
 #endif
-static int launch_attn_prefill(const AttnPrefillParams& ap, int n_heads, int head_dim, int rows, hipStream_t st) {
-    const dim3 grid(n_heads, (rows + 16 * LSK_PF_RT - 1) / (16 * LSK_PF_RT)), block(LSK_ATTN_THREADS);
-    if (head_dim == 128) hipLaunchKernelGGL((lsk_attn_prefill_kernel<128, LSK_PF_RT, LSK_PF_PREFETCH>), grid, block, 0, st, ap);
-    else hipLaunchKernelGGL((lsk_attn_prefill_kernel<64, LSK_PF_RT, LSK_PF_PREFETCH>), grid, block, 0, st, ap);
+template <int RT>
+static int launch_attn_prefill_rt(const AttnPrefillParams& ap, int n_heads, int head_dim, int rows, hipStream_t st) {
+    const dim3 grid(n_heads, (rows + 16 * RT - 1) / (16 * RT)), block(LSK_ATTN_THREADS);
+    if (head_dim == 128) hipLaunchKernelGGL((lsk_attn_prefill_kernel<128, RT, LSK_PF_PREFETCH>), grid, block, 0, st, ap);
+    else hipLaunchKernelGGL((lsk_attn_prefill_kernel<64, RT, LSK_PF_PREFETCH>), grid, block, 0, st, ap);
     HIP_OK(hipGetLastError());
     return 0;
+}
+// The kernel is bound by its K / V^T fragment reads from the L2, which every 16-row query tile of a workgroup shares: one tile per
+// workgroup 250 us at 2047 rows of llama2-7B, two 141, three 113 (four would need 256 + registers and spills: 154).  Short prompts want
+// MORE workgroups instead (511 rows: 512 workgroups of two tiles = one round of two per CU, 18.4 us; three tiles 19.4) --
+// profiles/r06_prefill_attention_variants.txt.  A row's result does not depend on the choice (lsk_attn.h).
+static int launch_attn_prefill(const AttnPrefillParams& ap, int n_heads, int head_dim, int rows, hipStream_t st) {
+    if (LSK_PF_RT == 1) return launch_attn_prefill_rt<1>(ap, n_heads, head_dim, rows, st);
+    if (LSK_PF_RT == 2) return launch_attn_prefill_rt<2>(ap, n_heads, head_dim, rows, st);
+    if (LSK_PF_RT == 3) return launch_attn_prefill_rt<3>(ap, n_heads, head_dim, rows, st);
+    return rows > LSK_PF_RT_LONG_ROWS ? launch_attn_prefill_rt<3>(ap, n_heads, head_dim, rows, st) : launch_attn_prefill_rt<2>(ap, n_heads, head_dim, rows, st);
 }
 
