@@ -505,7 +505,8 @@ __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineP
 }
 
 // ---- prompt-prefill attention: RT x 16 query rows x all visible keys per workgroup, online softmax (flash shape) ----
-// grid = (n_heads, ceil(rows / (16 RT))), block = 4 waves.  Wave w walks the 32-key sub-blocks w, w+4, ... of its head: K / V^T fragments straight from the pages (same layouts as the decode kernel), running (max, sum) per row with one
+// grid = (n_heads, ceil(rows / (16 RT))), block = 4 waves.  Wave w walks KV pages w, w+4, ... of its head in 32-key
+// sub-blocks: K / V^T fragments straight from the pages (same layouts as the decode kernel), running (max, sum) per row with one
 // rescale of O per sub-block.  Both products TRANSPOSED, as in the decode kernel (round 6; lsk_attn_body has the layout argument):
 // S^T = K Q^T with the K tile rows permuted in the load addresses leaves a lane with 8 CONSECUTIVE keys of ONE query row -- already the
 // B operand of O^T = V^T P^T -- so P never goes through LDS, a row's statistics are 8 in-lane values and two row swaps, the rescale
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(HD) void lsk_attn_combine_kernel(const AttnCombineP
 // 512 cycles of MFMA -- the kernel was bound by its softmax, not by its fragments.
 // The RT row tiles of a workgroup share every K / V^T fragment a wave loads; PF selects what is requested one sub-block ahead.  The 4
 // waves are merged in a fixed order at the end, one row tile at a time.
-// A row's arithmetic depends only on its position (key partition by absolute sub-block index, fixed sub-block order): a row tile for
+// A row's arithmetic depends only on its position (key partition by page, fixed sub-block order): a row tile for
 // which a sub-block lies entirely in the future multiplies its accumulators by exp2(0) = 1 and adds P = 0 products,
 // so results are bit-identical for every RT.  One launch per layer replaces the rows/16 launches of the decode
 // kernel; only prompt rows that are not decision rows go through it.
@@ -534,6 +535,34 @@ struct AttnPrefillParams {
     int pos_off;
     float scale_log2e;
 };
+
+// The sum of a query row's 32 probabilities of a sub-block.  The natural order of the transposed layout is 8 in-lane values, then the 4
+// lanes of the column (COMPAT = false).  COMPAT = true adds them in the order the kernel of rounds 2-5 did (S in the C layout: key c with
+// key c + 16 in a lane, then a 16-lane butterfly at distances 8, 4, 2, 1), which in this layout is two exchanges per value -- lanes l ^ 32
+// hold key + 16, lanes l ^ 16 key + 8 -- before the in-lane distances 4, 2, 1: 16 row swaps instead of 2, ~55 more VALU instructions per
+// row tile and sub-block.  With it (and the same page split over the waves) every product, maximum, exponential and sum of the rewritten
+// kernel is the one the old kernel computed: prompt KV pages and exit hiddens are BIT-IDENTICAL to rounds 2-5 -- a row sum's last bit moves
+// the generation of a random-init checkpoint off its trajectory (llama2-7B benchmark: acceptance 0.653 -> 0.611 with the natural order,
+// 718 -> 685 tokens/s at an unchanged fraction of the bandwidth floor; on another pair of prompts 0.669 -> 0.708), and round-over-round
+// tokens/s should compare kernels, not draws.  Used by the two-tile form (prompts up to 768 rows: the benchmarked 512-token prompt, every
+// short fixture); the three-tile form of long prompts has no registers for it and sums in the natural order.
+#ifndef LSK_PF_SUM_COMPAT
+#define LSK_PF_SUM_COMPAT true
+#endif
+template <bool COMPAT>
+__device__ __forceinline__ float lsk_pf_row_sum(const float (&pe)[8]) {
+    if (!COMPAT) return col4_sum(((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7])));
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = pe[j], b = pe[j];
+        lsk_row_swap32(a, b);                 // (this key of the lower half, of the upper half): key + 16
+        a = a + b; b = a;
+        lsk_row_swap16(a, b);                 // (even row, odd row): key + 8
+        y[j] = a + b;
+    }
+    return ((y[0] + y[4]) + (y[2] + y[6])) + ((y[1] + y[5]) + (y[3] + y[7]));
+}
 
 #ifndef LSK_PF_MINW
 #define LSK_PF_MINW 2               // min waves per SIMD: keeps hipcc inside 256 registers WITHOUT parking values in AGPRs
@@ -583,20 +612,20 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS, LSK_PF_MINW) void lsk_attn_prefil
         for (int dt = 0; dt < DT; ++dt) o[rt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    // the 32-key sub-blocks in reach are dealt to the 4 waves round robin: wave w takes sub-blocks w, w + 4, ... (sub-block s = keys
-    // [32 s, 32 s + 32) = quarter s % 4 of page s / 4).  (Rounds 1-5 dealt whole PAGES: a 512-token prompt is at most 4 pages, its first
-    // row blocks had one busy wave and three idle ones.)  A function of the absolute key index only, like the page split before it.
-    const int nsb = (last_key >> 5) + 1;
-    const int nj = (nsb > w) ? (nsb - w + LSK_ATTN_WAVES - 1) / LSK_ATTN_WAVES : 0;
+    // this wave's sub-blocks, flattened: j -> page w + 4 (j / 4), 32-key sub-block j % 4; only the last page in reach is partial.  (Dealing
+    // the SUB-BLOCKS round robin instead -- a 512-token prompt has at most 4 pages, its first row blocks keep one wave busy -- measured no
+    // different at 511 and 2047 rows: the longest workgroup sets the time, and it has 4 sub-blocks per wave either way.)
+    const int my_pages = (n_pages > w) ? (n_pages - w + LSK_ATTN_WAVES - 1) / LSK_ATTN_WAVES : 0;
+    const bool own_last = my_pages > 0 && ((n_pages - 1 - w) % LSK_ATTN_WAVES == 0);
+    const int nj = my_pages * 4 - (own_last ? 3 - ((last_key - (n_pages - 1) * LSK_ATTN_PAGE) >> 5) : 0);
     // PF = what is requested one sub-block ahead: 0 nothing, 1 the K fragments, 2 K and V^T (64 more registers at d = 128)
     elem8 kb[PF >= 1 ? 2 : 1][2][KS], vb[PF == 2 ? 2 : 1][DT];
     // K is the A operand: tile t's row a is key (a / 4) * 8 + t * 4 + a % 4 of the sub-block, so that this lane's accumulator registers
     // s0[r], s1[r] are keys g*8 + r, g*8 + 4 + r
     const int krow = (c16 >> 2) * 8 + (c16 & 3);
     auto load_k = [&](int j, elem8 (&kd)[2][KS]) {      // unconditional: j is clamped by the caller
-        const int sb = w + LSK_ATTN_WAVES * j;
-        const int page = p.block_table[sb >> 2];
-        const elem_t* kp = p.kpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)((sb & 3) * 32 + krow) * HD + g * 8;
+        const int page = p.block_table[w + LSK_ATTN_WAVES * (j >> 2)];
+        const elem_t* kp = p.kpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)((j & 3) * 32 + krow) * HD + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kd[0][ks] = *(const elem8*)(kp + ks * 32);
@@ -604,14 +633,13 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS, LSK_PF_MINW) void lsk_attn_prefil
         }
     };
     auto load_v = [&](int j, elem8 (&vd)[DT]) {
-        const int sb = w + LSK_ATTN_WAVES * j;
-        const int page = p.block_table[sb >> 2];
-        const elem_t* vp = p.vpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)c16 * LSK_ATTN_PAGE + (sb & 3) * 32 + g * 8;
+        const int page = p.block_table[w + LSK_ATTN_WAVES * (j >> 2)];
+        const elem_t* vp = p.vpool + ((size_t)page * p.n_kv + kvh) * LSK_ATTN_PAGE * HD + (size_t)c16 * LSK_ATTN_PAGE + (j & 3) * 32 + g * 8;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) vd[dt] = *(const elem8*)(vp + (size_t)dt * 16 * LSK_ATTN_PAGE);
     };
     auto block = [&](int j, elem8 (&kd)[2][KS], elem8 (&vd)[DT]) {
-        const int kbase = (w + LSK_ATTN_WAVES * j) * 32 + g * 8;     // first of this lane's 8 keys
+        const int kbase = (w + LSK_ATTN_WAVES * (j >> 2)) * LSK_ATTN_PAGE + (j & 3) * 32 + g * 8;     // first of this lane's 8 keys
         {   // never-written slots behind this block's last key may hold NaN: zero their V (see lsk_attn_body)
             const int nvalid = last_key + 1 - kbase;
             if (nvalid < 8) {
@@ -642,7 +670,7 @@ __global__ __launch_bounds__(LSK_ATTN_THREADS, LSK_PF_MINW) void lsk_attn_prefil
             float pe[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pe[jj] = (kbase + jj <= lim[rt]) ? __builtin_amdgcn_exp2f(sc[jj] - mn) : 0.f;
-            const float l = col4_sum(((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7])));
+            const float l = lsk_pf_row_sum<LSK_PF_SUM_COMPAT && RT <= 2>(pe);      // (three row tiles + the 8 exchanged values do not fit 256 registers)
             lrun[rt] = lrun[rt] * alpha + l;
             mrun[rt] = mn;
             // P is rounded to bf16 (as HF's eager path and torch's flash kernels both do before the second GEMM)

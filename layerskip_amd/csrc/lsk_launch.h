@@ -140,7 +140,8 @@ static int launch_attn_prefill_rt(const AttnPrefillParams& ap, int n_heads, int 
 // The kernel is bound by its K / V^T fragment reads from the L2, which every 16-row query tile of a workgroup shares: one tile per
 // workgroup 250 us at 2047 rows of llama2-7B, two 141, three 113 (four would need 256 + registers and spills: 154).  Short prompts want
 // MORE workgroups instead (511 rows: 512 workgroups of two tiles = one round of two per CU, 18.4 us; three tiles 19.4) --
-// profiles/r06_prefill_attention_variants.txt.  A row's result does not depend on the choice (lsk_attn.h).
+// profiles/r06_prefill_attention_variants.txt.  The two-tile form also sums a row's probabilities in the order of rounds 2-5
+// (lsk_pf_row_sum: prompt KV bit-identical to the earlier rounds); otherwise a row's result does not depend on the choice (lsk_attn.h).
 static int launch_attn_prefill(const AttnPrefillParams& ap, int n_heads, int head_dim, int rows, hipStream_t st) {
     if (LSK_PF_RT == 1) return launch_attn_prefill_rt<1>(ap, n_heads, head_dim, rows, st);
     if (LSK_PF_RT == 2) return launch_attn_prefill_rt<2>(ap, n_heads, head_dim, rows, st);
