@@ -188,6 +188,38 @@ def test_prefill_kernels_match_decode_kernels(gpu_device):
     eng.close()
 
 
+@pytest.mark.parametrize("shape,lengths", [("slice-7B", (255, 767, 1023, 1279, 2047)), ("slice-70B", (383, 1023, 1600)), ("slice-1B", (511, 1023, 2047))])
+def test_every_prefill_tile_shape_matches_the_decode_kernels(gpu_device, shape, lengths):
+    """The prefill launches pick their tile shape from the workgroup counts a prompt length gives (csrc/lsk_engine.hip: launch_big_qkv,
+    launch_big_resid; csrc/lsk_launch.h: two or three row tiles in the attention kernel): tiny models only ever reach the smallest shapes.
+    Real widths at prompt lengths on both sides of every threshold -- 64 x 192 / 128 x 192 / 128 x 256 / 128 x 384 q/k/v tiles (the
+    ragged last panel of llama2-70B's 640 tiles included), the 32- / 64- / 128-row K-split and the 128 x 256 pinned residual tiles, both
+    attention forms, d = 64 -- against 16-row passes of the decode kernels on the same rows: same rounding points, another summation
+    order."""
+    from layerskip_amd import _lib, synthetic
+    from layerskip_amd.engine import BUF_BULK, HipEngine
+    cfg = synthetic.make_config(shape, num_hidden_layers=2)
+    model = synthetic.build_model(cfg, seed=3, exit_layer=1, late_damping=0.1, dtype=torch.bfloat16, device=gpu_device, gen_device=gpu_device)
+    eng = HipEngine(model, max_ctx=max(lengths) + 64, max_prompt=max(lengths) + 1)
+    for n in lengths:
+        ids = synthetic.make_prompt(cfg.vocab_size, n, 100 + n)
+        outs = []
+        for threshold in (1 << 30, 1):
+            eng.set_option(_lib.LSK_OPT_BIG_THRESHOLD, threshold)
+            eng.reset()
+            eng.embed_rows(ids, BUF_BULK, 0)
+            eng.run_bulk(n, 0, eng.num_layers)
+            outs.append(eng.read_rows(BUF_BULK, 0, n).float())
+        torch.cuda.synchronize()
+        a, b = outs
+        assert torch.isfinite(b).all(), n
+        scale = a.abs().max().item()
+        assert (a - b).abs().max().item() <= 0.03 * scale, n
+        assert (a - b).abs().mean().item() <= 0.004 * scale, n
+    eng.close()
+    del model
+
+
 def test_fused_attention_combine_equals_two_kernel_form(gpu_device):
     """In-launch last-arriver combine (write-through partials + ticket) vs the separate combine kernel:
     bit-identical hidden states, for decode rows and a verify block, under repeated launches."""
