@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/s25
+mkdir -p $R/gpurun_out/s25   # (output directory: gpurun_out/s25)
 cd $R
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/s25/prof -- python tools/prefill_yardstick.py --out gpurun_out/s25/y.json > gpurun_out/s25/log.txt 2>&1
 python - <<'PY'
