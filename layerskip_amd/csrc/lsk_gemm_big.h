@@ -8,7 +8,8 @@
 // tiles: NTW = 2 is exactly one gate/up pair or one RoPE tile pair), one barrier per K-tile.  The block id is mapped
 // XCD-aware (see the kernel): the row blocks that share a weight panel run on ONE XCD, so the panel is fetched from
 // HBM once and re-read from that XCD's L2.  The host picks (NTW, MT, PB, NW, KS, TR) per projection and prompt length
-// (lsk_engine.hip, "Prefill tile shapes"); every shape without a K-split walks K in the same order, so those outputs are bit-identical.
+// (lsk_engine.hip, "Prefill tile shapes": by the workgroup count each shape would give); every shape without a K-split walks K in the same
+// order, so those outputs are bit-identical.
 // __launch_bounds__(threads, 2): without the min-waves bound hipcc budgets a 4-wave workgroup 512 registers per wave,
 // parks half of the weight ring in AGPRs and shuffles it back and forth (84 v_accvgpr moves per 128 MFMAs); with it
 // the same code takes 164-204 VGPRs, no AGPRs, two or three waves per SIMD.
@@ -51,11 +52,13 @@ struct BigGemmParams {
     int pos_off;
 };
 
-// NTW = packed 16-column tiles per wave: 4 or 2 (256- / 128-column workgroup tile; SwiGLU needs the gate/up PAIRS in one wave) or
-// 1 (64-column tile).  MT = 16-row tiles per workgroup (BM = 16 MT rows: 128, 64 or 32).  Every A fragment read from LDS feeds NTW
-// MFMAs and the LDS pipe is the first unit to saturate (one 1 KiB fragment read = 8 LDS cycles for 16 MFMA cycles, four SIMDs on one
-// LDS), so NTW sets the MFMA ceiling and MT x NTW the accumulator registers: (MT, NTW) = (8, 2) and (4, 4) both hold 64 accumulator
-// VGPRs at two waves per SIMD; (8, 4) needs 288 registers (one wave per SIMD, measured 2x slower).
+// NTW = packed 16-column tiles per wave: 2, 3 or 4 (SwiGLU needs the gate/up PAIRS in one wave: even NTW; q/k/v and the residual
+// projections take any).  MT = 16-row tiles per workgroup (BM = 16 MT rows: 128, 64 or 32).  NW = 4 or 8 waves side by side: the
+// workgroup tile is BM x (16 NTW NW) -- 64 x 128 ... 128 x 384.  MT x NTW sets the accumulator registers: (8, 2), (8, 3) and (4, 4) stay
+// at two or three waves per SIMD; (8, 4) needs 288 registers (one wave per SIMD, measured 2x slower).  Every A fragment read from LDS
+// feeds NTW MFMAs (one 1 KiB fragment read = 8 LDS cycles for 16 MFMA cycles, four SIMDs on one LDS); measured, that is NOT what bounds
+// the kernel: on every shape that compiles a CU sustains 3.5-3.9 TFLOP/s once it holds two waves per SIMD (profiles/
+// r06_gemm_big_bench_explore.txt), so the host picks the shape whose workgroup COUNT makes whole rounds on the 256 CUs (lsk_engine.hip).
 //
 // KS = K-split INSIDE the workgroup (round 6).  The N = hidden projections of a 512-row prompt are 256 workgroups of 64 x 128 for 256 CUs:
 // ONE 4-wave workgroup per CU, one wave per SIMD -- nothing to switch to while a wave waits for its fragments, its barrier or its LDS
