@@ -439,6 +439,13 @@ static int launch_attn(lsk_engine* e, const elem_t* q, elem_t* out, const elem_t
 #ifndef LSK_OPROJ_WGS
 #define LSK_OPROJ_WGS 0
 #endif
+// (measurement builds: -DLSK_GATEUP_WGS=N / -DLSK_HEAD_WGS=N override the workgroup count of the gate/up and lm_head launches alone)
+#ifndef LSK_GATEUP_WGS
+#define LSK_GATEUP_WGS 0
+#endif
+#ifndef LSK_HEAD_WGS
+#define LSK_HEAD_WGS 0
+#endif
 // decoder layers [lb, le) in place over rows of `x` (positions *base_ptr + pos_off + i)
 int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int pos_off, int lb, int le, hipStream_t st) {
     const lsk_config& c = e->cfg;
@@ -478,7 +485,7 @@ int lsk_run_layers_dev(lsk_engine* e, elem_t* x, int m, const int* base_ptr, int
             p.norm_w = lw.norm2; p.eps = c.rms_eps; p.act = e->act; p.ldact = c.intermediate;
             hipEvent_t ea = nullptr, eb = nullptr;
             LSK_TRY(profile_pair(e, LSK_PROF_GATEUP, m, (double)p.wp_bytes, &ea, &eb));
-            LSK_TRY((launch_gemm<PRO_RMS, EPI_SWIGLU>(p, e->target_wgs, st, nullptr, ea, eb)));
+            LSK_TRY((launch_gemm<PRO_RMS, EPI_SWIGLU>(p, LSK_GATEUP_WGS > 0 ? LSK_GATEUP_WGS : e->target_wgs, st, nullptr, ea, eb)));
         }
         {   // down_proj + residual
             GemmParams p{};
@@ -507,7 +514,7 @@ int lsk_run_head_dev(lsk_engine* e, const elem_t* x, int m, float* logits, int l
     int grid = 0;
     hipEvent_t ea = nullptr, eb = nullptr;
     LSK_TRY(profile_pair(e, LSK_PROF_HEAD, m, (double)p.wp_bytes, &ea, &eb));
-    LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, e->target_wgs, st, &grid, ea, eb)));
+    LSK_TRY((launch_gemm<PRO_RMS, EPI_HEAD>(p, LSK_HEAD_WGS > 0 ? LSK_HEAD_WGS : e->target_wgs, st, &grid, ea, eb)));
     if (grid > e->max_parts) return lsk_fail("internal: head grid %d > max_parts %d", grid, e->max_parts);
     if (tokens_dev == nullptr) {                                 // sample=True: the logits rows are what the caller wants, nobody reads an argmax
         if (kv_add) return lsk_fail("internal: a head without an argmax launch cannot advance the context");
